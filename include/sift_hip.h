@@ -1,0 +1,157 @@
+/*
+ * sift_hip.h -- C ABI of the MI355X (gfx950) SIFT detect / describe / match path.
+ *
+ * The reference (hunandy14/Sift) has no FFI of its own: its boundary is the C++
+ * class API (Sift, ImgRaw, Feature, Stitching).  The host classes in
+ * sift_amd/host/ keep that API and call the entry points below; each entry point
+ * names the reference code it stands in for (paths relative to the reference's
+ * Sift/ directory).  Plain C types only; the caller owns every host buffer, the
+ * context owns every device buffer.  No entry point throws; all return
+ * SIFT_HIP_OK (0) or a negative sift_hip_status.
+ *
+ * Threading: a context is bound to one device and one HIP stream and is not
+ * thread-safe.  Use one context per GPU (or per stream); distinct contexts may
+ * be driven concurrently from different threads.
+ */
+#ifndef SIFT_HIP_H
+#define SIFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sift_hip_ctx sift_hip_ctx;
+
+typedef enum sift_hip_status {
+    SIFT_HIP_OK = 0,
+    SIFT_HIP_ERR_ARG = -1,      /* null pointer, non-positive size, bad enum */
+    SIFT_HIP_ERR_NOSPC = -2,    /* output capacity too small; *n holds the needed count */
+    SIFT_HIP_ERR_HIP = -3,      /* a HIP runtime call failed (see sift_hip_last_error) */
+    SIFT_HIP_ERR_NOMEM = -4,    /* device allocation failed */
+    SIFT_HIP_ERR_SAME = -5,     /* in == out (the reference throws file_same, imglib/imglib.cpp:76-78) */
+    SIFT_HIP_ERR_NODEVICE = -6, /* no usable gfx950 device */
+    SIFT_HIP_ERR_LIMIT = -7     /* an internal fixed limit was exceeded (candidate table) */
+} sift_hip_status;
+
+/* Compile-time tunables of Sift.hpp:44-77 that the path reads, as run-time fields. */
+typedef struct sift_hip_params {
+    int32_t octaves;     /* 0 = the reference's own count, Sift.cpp:130-139 (getPyramidOctv) */
+    int32_t intvls;      /* SIFT_INTVLS (3); Gaussian levels per octave = intvls + 3 */
+    float sigma0;        /* SIFT_GauSigma (1.6f) */
+    float dx_thr;        /* SIFT_Dx (0.03f); the contrast test is |D| > dx_thr / 2 */
+    int32_t subpixel;    /* 0 = off, as shipped by the reference (call commented out at Sift.cpp:187);
+                            1 = Lowe refinement of matrix.hpp:140-196 rejects/relocates candidates */
+    int32_t blur_mode;   /* 0 = exact: float product, double accumulation in tap order
+                            (imglib/imglib.cpp:85-117); 1 = fast: fp32 FMA accumulation */
+    float contr_thr;     /* SIFT_CONTR_THR (0.05), used only when subpixel = 1 */
+    int32_t reserved;
+} sift_hip_params;
+
+/* One keypoint + descriptor: the fields of `struct Feature` (imagedata.hpp:63-86)
+ * that Sift::pyramid() fills.  descr holds the integer-valued descriptor
+ * (Sift.cpp:416-420: min(255, (int)(512 * v))) as bytes. */
+typedef struct sift_hip_feat {
+    float size;      /* octave scale: 2, 1, 0.5, ... */
+    int32_t kai;     /* DoG layer 1..intvls */
+    float sigmaOCT;  /* integer-truncated sigma (Sift.cpp:229,287) */
+    int32_t x, y;    /* octave-pixel coordinates */
+    float mm;        /* orientation-histogram bin value */
+    int32_t sita;    /* orientation in degrees, multiple of 10 */
+    uint8_t descr[128];
+} sift_hip_feat;
+
+/* ---- context -------------------------------------------------------------------- */
+int sift_hip_create(sift_hip_ctx** ctx, int device);
+int sift_hip_destroy(sift_hip_ctx* ctx);
+void sift_hip_default_params(sift_hip_params* p);
+const char* sift_hip_strerror(int status);
+const char* sift_hip_last_error(const sift_hip_ctx* ctx); /* text of the last HIP failure */
+/* HIP stream the context launches on (a hipStream_t), for callers that order
+ * their own device work against it. */
+void* sift_hip_stream(sift_hip_ctx* ctx);
+int sift_hip_synchronize(sift_hip_ctx* ctx);
+
+/* ---- extract: replaces the body of Sift::pyramid(), Sift.cpp:140-225 -------------
+ * img: host pointer, row-major top-down floats in [0,1]; channels = 1 (gray) or 3
+ * (interleaved RGB, converted as ImgRaw::ConverGray, Imgraw.cpp:257-269).
+ * out: caller-allocated array of cap features, filled in the reference's order
+ * (octave, layer, row, column, orientation bin -- Sift.cpp:207-224).
+ * hist: optional (may be NULL) cap x 128 floats: the clamped histogram the
+ * descriptor bytes are quantised from.
+ * *n receives the feature count; if it exceeds cap the call returns
+ * SIFT_HIP_ERR_NOSPC, *n is the needed capacity and out holds the first cap. */
+int sift_hip_extract(sift_hip_ctx* ctx, const float* img, int w, int h, int channels,
+                     const sift_hip_params* params, sift_hip_feat* out, int cap, int* n, float* hist);
+/* Same, with the image already in device memory (gray only); out/hist stay host. */
+int sift_hip_extract_dev(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
+                         const sift_hip_params* params, sift_hip_feat* out, int cap, int* n, float* hist);
+/* nframes gray frames of equal size, contiguous on the host; frame f writes
+ * out[f*cap .. f*cap + n[f]) (the per-frame loop of StitchImg, Sift_main.cpp:31-48).
+ * Uploads overlap the previous frame's kernels. */
+int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h, int nframes,
+                           const sift_hip_params* params, sift_hip_feat* out, int cap, int* n);
+/* Device-resident variant of the batch call: frames in device memory. */
+int sift_hip_extract_batch_dev(sift_hip_ctx* ctx, const float* d_frames, int w, int h, int nframes,
+                               const sift_hip_params* params, sift_hip_feat* out, int cap, int* n);
+
+/* ---- image ops kept public by the reference (imglib/imglib.hpp:18-57) ----------- */
+/* Gaus::gau_matrix, imglib.cpp:127-155 (host arithmetic, no GPU work). Returns the
+ * tap count, or -needed if cap is too small. */
+int sift_hip_gau_matrix(float p, int mat_len, float* taps, int cap);
+/* Gaus::GauBlur, imglib.cpp:72-118: host in -> host out, w*h floats. */
+int sift_hip_gau_blur(sift_hip_ctx* ctx, const float* in, float* out, int w, int h, float p, int blur_mode);
+/* Scaling::first / ImgRaw::first, imglib.cpp:227-252: out is floor(w*ratio) x floor(h*ratio). */
+int sift_hip_first(sift_hip_ctx* ctx, const float* in, int w, int h, float ratio, float* out);
+/* ImgRaw::ConverGray, Imgraw.cpp:257-269: n RGB pixels -> n gray floats. */
+int sift_hip_convert_gray(sift_hip_ctx* ctx, const float* rgb, int n, float* gray);
+/* Gaussian and DoG levels of one octave as Sift::pyramid builds them
+ * (Sift.cpp:145-168); gau: (intvls+3)*ow*oh floats, dog: (intvls+2)*ow*oh floats,
+ * either may be NULL.  ow/oh receive the octave size. */
+int sift_hip_octave_levels(sift_hip_ctx* ctx, const float* gray, int w, int h, const sift_hip_params* params,
+                           int octave, float* gau, float* dog, int* ow, int* oh);
+/* getPyramidOctv, Sift.cpp:130-139. */
+int sift_hip_pyramid_octaves(int w, int h);
+
+/* ---- match: replaces kdtreeMatchFeat / forceMatchFeat, Sift.cpp:537-584 ----------
+ * Exact nearest / second-nearest neighbour of every query among the references
+ * over 128-byte descriptors (squared L2 in int32, exact), lowest reference index
+ * winning ties (forceMatchFeat's strict '<').  ratio_form 0: accept iff
+ * d1 < d2 * ratio in float and nr >= 2 (the live call site, Sift.cpp:573-578);
+ * ratio_form 1: accept iff (d1 / d2) < ratio (forceMatchFeat, Sift.cpp:563).
+ * best[i] = reference index or -1; d1/d2 (optional) = the two squared distances
+ * (INT32_MAX where no such reference exists). */
+int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t* r, int nr, float ratio,
+                      int ratio_form, int32_t* best, int32_t* d1, int32_t* d2);
+/* All pointers in device memory; runs on the context's stream, no host sync. */
+int sift_hip_match_u8_dev(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
+                          int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
+
+/* ---- measurement ------------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the
+ * context's stream; totals are kept per kernel class. */
+enum {
+    SIFT_HIP_K_RESAMPLE = 0,
+    SIFT_HIP_K_BLUR_ROW = 1,
+    SIFT_HIP_K_BLUR_COL = 2,
+    SIFT_HIP_K_DETECT = 3,
+    SIFT_HIP_K_COMPACT = 4,
+    SIFT_HIP_K_ORIENT = 5,
+    SIFT_HIP_K_EMIT = 6,
+    SIFT_HIP_K_DESCR = 7,
+    SIFT_HIP_K_MATCH = 8,
+    SIFT_HIP_K_GRAY = 9,
+    SIFT_HIP_K_COUNT = 10
+};
+int sift_hip_profile(sift_hip_ctx* ctx, int enable);
+/* Synchronises, then fills ms[k] = summed kernel time and launches[k] = launch
+ * count of class k since the last reset; both arrays hold SIFT_HIP_K_COUNT entries. */
+int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset);
+const char* sift_hip_kernel_class_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIFT_HIP_H */

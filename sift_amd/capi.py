@@ -1,0 +1,295 @@
+"""ctypes binding of the C ABI declared in include/sift_hip.h.
+
+There is no fallback: if the shared library is missing or the device is not a
+gfx950 GPU the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+#: numpy view of ``sift_hip_feat`` (156 bytes, no padding)
+FEAT_DTYPE = np.dtype(
+    [
+        ("size", "<f4"),
+        ("kai", "<i4"),
+        ("sigmaOCT", "<f4"),
+        ("x", "<i4"),
+        ("y", "<i4"),
+        ("mm", "<f4"),
+        ("sita", "<i4"),
+        ("descr", "u1", (128,)),
+    ]
+)
+assert FEAT_DTYPE.itemsize == 156
+
+KERNEL_CLASSES = ("resample", "blur_row", "blur_col", "detect", "compact", "orient", "emit", "descr", "match", "gray")
+
+OK, ERR_ARG, ERR_NOSPC, ERR_HIP, ERR_NOMEM, ERR_SAME, ERR_NODEVICE, ERR_LIMIT = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("octaves", C.c_int32),
+        ("intvls", C.c_int32),
+        ("sigma0", C.c_float),
+        ("dx_thr", C.c_float),
+        ("subpixel", C.c_int32),
+        ("blur_mode", C.c_int32),
+        ("contr_thr", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
+@dataclass
+class SiftParams:
+    """Run-time form of the tunables of the reference's Sift.hpp:44-77."""
+
+    octaves: int = 0
+    intvls: int = 3
+    sigma0: float = 1.6
+    dx_thr: float = 0.03
+    subpixel: int = 0
+    blur_mode: int = 0
+    contr_thr: float = 0.05
+
+    def _c(self) -> _Params:
+        return _Params(self.octaves, self.intvls, self.sigma0, self.dx_thr, self.subpixel, self.blur_mode,
+                       self.contr_thr, 0)
+
+
+class SiftHipError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"sift_hip status {status}: {msg}")
+        self.status = status
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libsift_hip.so")
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libsift_hip.so and declares every prototype of sift_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    P = C.POINTER(_Params)
+    protos = {
+        "sift_hip_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "sift_hip_destroy": (C.c_int, [vp]),
+        "sift_hip_default_params": (None, [P]),
+        "sift_hip_strerror": (C.c_char_p, [C.c_int]),
+        "sift_hip_last_error": (C.c_char_p, [vp]),
+        "sift_hip_stream": (vp, [vp]),
+        "sift_hip_synchronize": (C.c_int, [vp]),
+        "sift_hip_extract": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip, vp]),
+        "sift_hip_extract_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, P, vp, C.c_int, ip, vp]),
+        "sift_hip_extract_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip]),
+        "sift_hip_extract_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip]),
+        "sift_hip_gau_matrix": (C.c_int, [C.c_float, C.c_int, fp, C.c_int]),
+        "sift_hip_gau_blur": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int]),
+        "sift_hip_first": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+        "sift_hip_convert_gray": (C.c_int, [vp, vp, C.c_int, vp]),
+        "sift_hip_octave_levels": (C.c_int, [vp, vp, C.c_int, C.c_int, P, C.c_int, vp, vp, ip, ip]),
+        "sift_hip_pyramid_octaves": (C.c_int, [C.c_int, C.c_int]),
+        "sift_hip_match_u8": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+        "sift_hip_match_u8_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+        "sift_hip_profile": (C.c_int, [vp, C.c_int]),
+        "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
+        "sift_hip_kernel_class_name": (C.c_char_p, [C.c_int]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError here = the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    lib._protos = tuple(protos)
+    _lib = lib
+    return lib
+
+
+def gau_matrix(p: float, mat_len: int = 0) -> np.ndarray:
+    """Gaus::gau_matrix (imglib.cpp:127-155); host arithmetic inside the library."""
+    lib = load_library()
+    buf = np.zeros(8192, np.float32)
+    n = lib.sift_hip_gau_matrix(p, mat_len, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size)
+    if n < 0:
+        raise SiftHipError(n, "gau_matrix")
+    return buf[:n].copy()
+
+
+def pyramid_octaves(w: int, h: int) -> int:
+    return load_library().sift_hip_pyramid_octaves(w, h)
+
+
+def _ptr(a) -> C.c_void_p:
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return C.c_void_p(a.data_ptr())  # torch tensor (device or host)
+
+
+def _f32(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class SiftHip:
+    """One context = one GPU + one HIP stream (not thread-safe)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.sift_hip_create(C.byref(h), device)
+        if rc != OK:
+            raise SiftHipError(rc, self.lib.sift_hip_strerror(rc).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sift_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, allow=()):
+        if rc != OK and rc not in allow:
+            detail = self.lib.sift_hip_last_error(self.h).decode()
+            raise SiftHipError(rc, self.lib.sift_hip_strerror(rc).decode() + (f" ({detail})" if detail else ""))
+        return rc
+
+    def synchronize(self):
+        self._check(self.lib.sift_hip_synchronize(self.h))
+
+    # ---- extract ---------------------------------------------------------------
+    def extract(self, img: np.ndarray, params: SiftParams | None = None, cap: int = 1 << 16, want_hist=False):
+        """img: HxW gray or HxWx3 RGB float32 in [0,1] on the host.
+        Returns (features[FEAT_DTYPE], hist or None)."""
+        img = _f32(img)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        h, w = img.shape[:2]
+        prm = (params or SiftParams())._c()
+        while True:
+            out = np.zeros(cap, FEAT_DTYPE)
+            hist = np.zeros((cap, 128), np.float32) if want_hist else None
+            n = C.c_int(0)
+            rc = self.lib.sift_hip_extract(self.h, _ptr(img), w, h, ch, C.byref(prm), _ptr(out), cap, C.byref(n),
+                                           _ptr(hist))
+            if rc == ERR_NOSPC:
+                cap = n.value
+                continue
+            self._check(rc)
+            return out[: n.value], (hist[: n.value] if want_hist else None)
+
+    def extract_dev(self, d_gray, w: int, h: int, params: SiftParams | None, out: np.ndarray, hist=None) -> int:
+        """d_gray: device pointer (int) or torch CUDA tensor; out: preallocated FEAT_DTYPE array."""
+        prm = (params or SiftParams())._c()
+        n = C.c_int(0)
+        rc = self.lib.sift_hip_extract_dev(self.h, _ptr(d_gray), w, h, C.byref(prm), _ptr(out), out.shape[0],
+                                           C.byref(n), _ptr(hist))
+        self._check(rc, allow=(ERR_NOSPC,))
+        return n.value
+
+    def extract_batch(self, frames: np.ndarray, params: SiftParams | None = None, cap: int = 1 << 15):
+        frames = _f32(frames)
+        nf, h, w = frames.shape
+        prm = (params or SiftParams())._c()
+        out = np.zeros((nf, cap), FEAT_DTYPE)
+        n = np.zeros(nf, np.int32)
+        rc = self.lib.sift_hip_extract_batch(self.h, _ptr(frames), w, h, nf, C.byref(prm), _ptr(out), cap,
+                                             n.ctypes.data_as(C.POINTER(C.c_int)))
+        self._check(rc, allow=(ERR_NOSPC,))
+        return out, n
+
+    def extract_batch_dev(self, d_frames, w: int, h: int, nframes: int, params: SiftParams | None, out: np.ndarray,
+                          n: np.ndarray):
+        prm = (params or SiftParams())._c()
+        rc = self.lib.sift_hip_extract_batch_dev(self.h, _ptr(d_frames), w, h, nframes, C.byref(prm), _ptr(out),
+                                                 out.shape[1], n.ctypes.data_as(C.POINTER(C.c_int)))
+        self._check(rc, allow=(ERR_NOSPC,))
+        return rc
+
+    # ---- image ops ----------------------------------------------------------------
+    def gau_blur(self, img: np.ndarray, p: float, blur_mode: int = 0) -> np.ndarray:
+        img = _f32(img)
+        h, w = img.shape
+        out = np.empty_like(img)
+        self._check(self.lib.sift_hip_gau_blur(self.h, _ptr(img), _ptr(out), w, h, p, blur_mode))
+        return out
+
+    def first(self, img: np.ndarray, ratio: float) -> np.ndarray:
+        img = _f32(img)
+        h, w = img.shape
+        nh = int(np.floor(np.float32(h) * np.float32(ratio)))
+        nw = int(np.floor(np.float32(w) * np.float32(ratio)))
+        out = np.empty((nh, nw), np.float32)
+        self._check(self.lib.sift_hip_first(self.h, _ptr(img), w, h, ratio, _ptr(out)))
+        return out
+
+    def convert_gray(self, rgb: np.ndarray) -> np.ndarray:
+        rgb = _f32(rgb)
+        n = rgb.size // 3
+        out = np.empty(rgb.shape[:-1], np.float32)
+        self._check(self.lib.sift_hip_convert_gray(self.h, _ptr(rgb), n, _ptr(out)))
+        return out
+
+    def octave_levels(self, gray: np.ndarray, octave: int, params: SiftParams | None = None):
+        gray = _f32(gray)
+        h, w = gray.shape
+        p = params or SiftParams()
+        size = np.float32(2.0) / np.float32(2.0 ** octave)
+        ow, oh = int(np.float32(w) * size), int(np.float32(h) * size)
+        gau = np.empty((p.intvls + 3, oh, ow), np.float32)
+        dog = np.empty((p.intvls + 2, oh, ow), np.float32)
+        cw, chh = C.c_int(0), C.c_int(0)
+        prm = p._c()
+        self._check(self.lib.sift_hip_octave_levels(self.h, _ptr(gray), w, h, C.byref(prm), octave, _ptr(gau),
+                                                    _ptr(dog), C.byref(cw), C.byref(chh)))
+        assert (cw.value, chh.value) == (ow, oh)
+        return gau, dog
+
+    # ---- match --------------------------------------------------------------------
+    def match_u8(self, q: np.ndarray, r: np.ndarray, ratio: float = 0.4, ratio_form: int = 0):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 128)
+        r = np.ascontiguousarray(r, np.uint8).reshape(-1, 128)
+        nq, nr = q.shape[0], r.shape[0]
+        best = np.full(nq, -1, np.int32)
+        d1 = np.zeros(nq, np.int32)
+        d2 = np.zeros(nq, np.int32)
+        self._check(self.lib.sift_hip_match_u8(self.h, _ptr(q), nq, _ptr(r), nr, ratio, ratio_form, _ptr(best),
+                                               _ptr(d1), _ptr(d2)))
+        return best, d1, d2
+
+    def match_u8_dev(self, d_q, nq: int, d_r, nr: int, ratio: float, ratio_form: int, d_best, d_d1=None, d_d2=None):
+        self._check(self.lib.sift_hip_match_u8_dev(self.h, _ptr(d_q), nq, _ptr(d_r), nr, ratio, ratio_form,
+                                                   _ptr(d_best), _ptr(d_d1), _ptr(d_d2)))
+
+    # ---- measurement ----------------------------------------------------------------
+    def profile(self, enable: bool):
+        self._check(self.lib.sift_hip_profile(self.h, int(enable)))
+
+    def profile_read(self, reset: bool = True):
+        ms = np.zeros(len(KERNEL_CLASSES), np.float32)
+        cnt = np.zeros(len(KERNEL_CLASSES), np.int32)
+        self._check(self.lib.sift_hip_profile_read(self.h, ms.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   cnt.ctypes.data_as(C.POINTER(C.c_int)), int(reset)))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_CLASSES)}

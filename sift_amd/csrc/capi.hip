@@ -1,0 +1,609 @@
+// C ABI of libsift_hip.so (declared in include/sift_hip.h): context, workspace,
+// the host-side constants of the pyramid (sigmas, taps, radii) and the launch
+// sequence of the extract and match paths.  No CPU fallback exists: every entry
+// point that does image or descriptor arithmetic runs the HIP kernels.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "internal.h"
+
+using namespace sifthip;
+
+namespace sifthip {
+
+bool hip_ok(sift_hip_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+int ensure(sift_hip_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return SIFT_HIP_OK;
+    if (b.p) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        ctx->last_error = "hipMalloc failed for " + std::to_string(want) + " bytes";
+        return SIFT_HIP_ERR_NOMEM;
+    }
+    b.cap = want;
+    return SIFT_HIP_OK;
+}
+
+int ensure_pinned(sift_hip_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return SIFT_HIP_OK;
+    if (b.p) {
+        hipStreamSynchronize(ctx->stream);
+        hipHostFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        ctx->last_error = "hipHostMalloc failed";
+        return SIFT_HIP_ERR_NOMEM;
+    }
+    b.cap = want;
+    return SIFT_HIP_OK;
+}
+
+void prof_begin(sift_hip_ctx* ctx, int cls) {
+    sift_hip_ctx::Ev ev;
+    ev.cls = cls;
+    for (hipEvent_t* e : {&ev.a, &ev.b}) {
+        if (!ctx->free_events.empty()) {
+            *e = ctx->free_events.back();
+            ctx->free_events.pop_back();
+        } else {
+            hipEventCreate(e);
+        }
+    }
+    hipEventRecord(ev.a, ctx->stream);
+    ctx->events.push_back(ev);
+}
+
+void prof_end(sift_hip_ctx* ctx) { hipEventRecord(ctx->events.back().b, ctx->stream); }
+
+// ---- host constants ------------------------------------------------------------
+// Gaus::gau_meth / Gaus::gau_matrix, imglib/imglib.cpp:120-155, same operand types.
+static float gau_meth(size_t r, float p) {
+    float two = 2.0;
+    float num = std::exp(-std::pow((double)r, (double)two) / (two * std::pow(p, two)));
+    num /= std::sqrt(two * 3.14159265358979323846) * p;
+    return num;
+}
+
+static std::vector<float> gau_matrix(float p, size_t mat_len) {
+    std::vector<float> g;
+    if (mat_len == 0) mat_len = (int)(std::round((p * 6 + 1))) | 1;
+    if (mat_len % 2 == 0) ++mat_len;
+    g.resize(mat_len);
+    float sum = 0;
+    for (int i = 0, j = (int)(mat_len / 2); j < (int)mat_len; ++i, ++j) {
+        float temp;
+        if (i) {
+            temp = gau_meth(i, p);
+            g[j] = temp;
+            g[mat_len - j - 1] = temp;
+            sum += temp += temp;
+        } else {
+            g[j] = gau_meth(i, p);
+            sum += g[j];
+        }
+    }
+    for (auto& v : g) v /= sum;
+    return g;
+}
+
+// getPyramidOctv, Sift.cpp:130-139
+static int pyramid_octaves(size_t width, size_t height) {
+    int n = 1;
+    for (float Limit = 1.0; Limit < width || Limit < height; ++n) Limit = powf(2.0, n);
+    if (n < 7) n = 1; else n -= 6;
+    return n;
+}
+
+static bool same_params(const sift_hip_params& a, const sift_hip_params& b) {
+    return a.octaves == b.octaves && a.intvls == b.intvls && a.sigma0 == b.sigma0 && a.dx_thr == b.dx_thr &&
+           a.subpixel == b.subpixel && a.blur_mode == b.blur_mode && a.contr_thr == b.contr_thr;
+}
+
+// Everything Sift::pyramid derives from (w, h, params) before touching pixels.
+static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& prm) {
+    Plan& pl = ctx->plan;
+    if (pl.valid && pl.w == w && pl.h == h && same_params(pl.prm, prm)) return SIFT_HIP_OK;
+    pl = Plan();
+    pl.w = w;
+    pl.h = h;
+    pl.prm = prm;
+    const int pyWidth = prm.intvls + 3;
+    const int octvs = prm.octaves > 0 ? prm.octaves : pyramid_octaves((size_t)w, (size_t)h);
+    // cos/sin of the 36 possible orientations, taken in DEGREES as radians (Sift.cpp:351-352)
+    for (int k = 0; k < 36; k++) pl.table.push_back(std::cos((float)(k * 10)));
+    for (int k = 0; k < 36; k++) pl.table.push_back(std::sin((float)(k * 10)));
+    float curr_size = 2.f, coef = 1.f;
+    for (int ph = 0; ph < octvs; ph++, curr_size /= 2.f, coef *= 2.f) {
+        OctavePlan oc;
+        oc.curr_size = curr_size;
+        oc.coef = coef;
+        oc.W = (int)(size_t)((uint32_t)w * curr_size);
+        oc.H = (int)(size_t)((uint32_t)h * curr_size);
+        if (oc.W < 2 || oc.H < 2) break;
+        for (int i = 0; i < pyWidth; i++) {
+            // Sift.cpp:152 (level 0) and :155 (levels >= 1)
+            const float s = (i == 0) ? prm.sigma0 * coef : prm.sigma0 * powf(std::sqrt(2.0), (size_t)i) * coef;
+            std::vector<float> g = gau_matrix(s, 0);
+            oc.sigma.push_back(s);
+            oc.tap_off.push_back((int)pl.table.size());
+            oc.tap_len.push_back((int)g.size());
+            pl.table.insert(pl.table.end(), g.begin(), g.end());
+            while (pl.table.size() & 7) pl.table.push_back(0.f);
+        }
+        for (int li = 1; li <= prm.intvls; li++) {
+            const size_t r = curr_size * 3. * 1.5 * (li + 1);                           // Sift.cpp:177
+            const float cs = prm.sigma0 * powf(std::sqrt(2.0), (size_t)li) * coef;      // Sift.cpp:183
+            std::vector<float> g = gau_matrix(cs, r * 2 + 1);                           // Sift.cpp:267
+            oc.radius.push_back((int)r);
+            oc.curr_sigma.push_back(cs);
+            oc.wts_off.push_back((int)pl.table.size());
+            pl.table.insert(pl.table.end(), g.begin(), g.end());
+            while (pl.table.size() & 7) pl.table.push_back(0.f);
+        }
+        pl.oct.push_back(oc);
+    }
+    int rc = ensure(ctx, ctx->table, pl.table.size() * sizeof(float));
+    if (rc) return rc;
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->table.p, pl.table.data(), pl.table.size() * sizeof(float),
+                                    hipMemcpyHostToDevice, ctx->stream), "upload tap table"))
+        return SIFT_HIP_ERR_HIP;
+    std::vector<LayerConsts> lc;
+    for (const OctavePlan& oc : pl.oct)
+        for (int li = 0; li < prm.intvls; li++)
+            lc.push_back(LayerConsts{oc.radius[li], oc.wts_off[li], oc.curr_sigma[li], (float)(int)oc.curr_sigma[li]});
+    rc = ensure(ctx, ctx->layer_consts, std::max<size_t>(1, lc.size()) * sizeof(LayerConsts));
+    if (rc) return rc;
+    if (!lc.empty() &&
+        !hip_ok(ctx, hipMemcpyAsync(ctx->layer_consts.p, lc.data(), lc.size() * sizeof(LayerConsts),
+                                    hipMemcpyHostToDevice, ctx->stream), "upload layer constants"))
+        return SIFT_HIP_ERR_HIP;
+    // the uploads read pageable host memory: finish them before the vectors move
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "plan upload")) return SIFT_HIP_ERR_HIP;
+    pl.valid = true;
+    return SIFT_HIP_OK;
+}
+
+// Gaussian + DoG levels of octave `oi` from the gray image on the device.
+static int run_octave_pyramid(sift_hip_ctx* ctx, const float* d_gray, int oi) {
+    const Plan& pl = ctx->plan;
+    const OctavePlan& oc = pl.oct[oi];
+    const size_t PX = (size_t)oc.W * oc.H;
+    const int pyWidth = pl.prm.intvls + 3;
+    int rc;
+    if ((rc = ensure(ctx, ctx->base, PX * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->tmp, PX * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->gau_all, PX * 4 * pyWidth))) return rc;
+    if ((rc = ensure(ctx, ctx->dog_all, PX * 4 * (pyWidth - 1)))) return rc;
+    float* base = (float*)ctx->base.p;
+    float* tmp = (float*)ctx->tmp.p;
+    float* gau = (float*)ctx->gau_all.p;
+    float* dog = (float*)ctx->dog_all.p;
+    const float* taps = (const float*)ctx->table.p;
+    launch_first(ctx, d_gray, pl.w, pl.h, oc.curr_size, base, oc.W, oc.H);
+    for (int i = 0; i < pyWidth; i++) {
+        const float* src = (i == 0) ? base : gau + (size_t)(i - 1) * PX;
+        launch_blur(ctx, src, tmp, gau + (size_t)i * PX, oc.W, oc.H, taps + oc.tap_off[i], oc.tap_len[i],
+                    pl.prm.blur_mode, i ? src : nullptr, i ? dog + (size_t)(i - 1) * PX : nullptr);
+    }
+    return SIFT_HIP_OK;
+}
+
+static int check_async(sift_hip_ctx* ctx, const char* what) {
+    return hip_ok(ctx, hipGetLastError(), what) ? SIFT_HIP_OK : SIFT_HIP_ERR_HIP;
+}
+
+// The whole of Sift::pyramid for one device-resident gray frame; results stay on
+// the device (ctx->feat / ctx->hist / counters).  No host synchronisation.
+static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params& prm,
+                           int feat_cap, int cand_cap, bool want_hist) {
+    int rc = build_plan(ctx, w, h, prm);
+    if (rc) return rc;
+    const Plan& pl = ctx->plan;
+    if ((rc = ensure(ctx, ctx->counters, CNT_SLOTS * sizeof(int)))) return rc;
+    if ((rc = ensure(ctx, ctx->feat, (size_t)std::max(1, feat_cap) * sizeof(sift_hip_feat)))) return rc;
+    if (want_hist && (rc = ensure(ctx, ctx->hist, (size_t)std::max(1, feat_cap) * 128 * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->cand, (size_t)cand_cap * sizeof(Cand)))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_mask, (size_t)cand_cap * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_mm, (size_t)cand_cap * 36 * sizeof(float)))) return rc;
+    if (!hip_ok(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_SLOTS * sizeof(int), ctx->stream), "reset counters"))
+        return SIFT_HIP_ERR_HIP;
+    const float thr = (float)((double)prm.dx_thr / 2.0);
+    for (int oi = 0; oi < (int)pl.oct.size(); oi++) {
+        const OctavePlan& oc = pl.oct[oi];
+        const size_t PX = (size_t)oc.W * oc.H;
+        const int WW = (oc.W + 63) / 64;
+        const int nrows = prm.intvls * oc.H;
+        if ((rc = ensure(ctx, ctx->masks, (size_t)nrows * WW * 8))) return rc;
+        if ((rc = ensure(ctx, ctx->row_cnt, (size_t)nrows * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->row_off, (size_t)nrows * 4))) return rc;
+        if ((rc = run_octave_pyramid(ctx, d_gray, oi))) return rc;
+        const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
+        launch_detect(ctx, (const float*)ctx->dog_all.p, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap);
+        launch_orient(ctx, (const float*)ctx->dog_all.p, PX, oc.W, d_lc, (const float*)ctx->table.p);
+        launch_emit(ctx, oc.curr_size, d_lc, feat_cap);
+        launch_descr(ctx, (const float*)ctx->gau_all.p, PX, oc.W, oc.H, (const float*)ctx->table.p, feat_cap,
+                     want_hist ? (float*)ctx->hist.p : nullptr);
+    }
+    return check_async(ctx, "extract launch");
+}
+
+// Copies the counters back, then the features (and histograms) that fit.
+static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow) {
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, CNT_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
+                                    ctx->stream), "read counters"))
+        return SIFT_HIP_ERR_HIP;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "extract")) return SIFT_HIP_ERR_HIP;
+    *cand_overflow = ctx->h_counters[CNT_CAND_OVERFLOW];
+    if (*cand_overflow) return SIFT_HIP_OK;
+    const int total = ctx->h_counters[CNT_FEAT_TOTAL];
+    *n = total;
+    const int m = std::min(total, cap);
+    if (m > 0) {
+        if (!hip_ok(ctx, hipMemcpyAsync(out, ctx->feat.p, (size_t)m * sizeof(sift_hip_feat), hipMemcpyDeviceToHost,
+                                        ctx->stream), "read features"))
+            return SIFT_HIP_ERR_HIP;
+        if (hist && !hip_ok(ctx, hipMemcpyAsync(hist, ctx->hist.p, (size_t)m * 128 * sizeof(float),
+                                                hipMemcpyDeviceToHost, ctx->stream), "read histograms"))
+            return SIFT_HIP_ERR_HIP;
+        if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "read features")) return SIFT_HIP_ERR_HIP;
+    }
+    return total > cap ? SIFT_HIP_ERR_NOSPC : SIFT_HIP_OK;
+}
+
+static int extract_dev_impl(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params* params,
+                            sift_hip_feat* out, int cap, int* n, float* hist) {
+    sift_hip_params prm;
+    if (params) prm = *params; else sift_hip_default_params(&prm);
+    if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || !(prm.sigma0 > 0.f)) return SIFT_HIP_ERR_ARG;
+    int cand_cap = std::max(ctx->cand_cap, std::max(cap, 1 << 16));
+    for (int attempt = 0; attempt < 4; attempt++) {
+        ctx->cand_cap = cand_cap;
+        int rc = enqueue_extract(ctx, d_gray, w, h, prm, cap, cand_cap, hist != nullptr);
+        if (rc) return rc;
+        int overflow = 0;
+        rc = fetch_features(ctx, out, cap, n, hist, &overflow);
+        if (!overflow) return rc;
+        cand_cap = overflow + overflow / 4;  // the candidate table was too small: grow and redo
+    }
+    return SIFT_HIP_ERR_LIMIT;
+}
+
+static bool bad_ctx(sift_hip_ctx* ctx) {
+    if (!ctx) return true;
+    return hipSetDevice(ctx->device) != hipSuccess;
+}
+
+}  // namespace sifthip
+
+extern "C" {
+
+int sift_hip_create(sift_hip_ctx** out, int device) {
+    if (!out) return SIFT_HIP_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        (void)hipGetLastError();
+        return SIFT_HIP_ERR_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SIFT_HIP_ERR_NODEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SIFT_HIP_ERR_NODEVICE;  // kernels are gfx950-only
+    if (hipSetDevice(device) != hipSuccess) return SIFT_HIP_ERR_NODEVICE;
+    sift_hip_ctx* ctx = new (std::nothrow) sift_hip_ctx();
+    if (!ctx) return SIFT_HIP_ERR_NOMEM;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counters, CNT_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        sift_hip_destroy(ctx);
+        return SIFT_HIP_ERR_HIP;
+    }
+    *out = ctx;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_destroy(sift_hip_ctx* ctx) {
+    if (!ctx) return SIFT_HIP_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
+    DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->base, &ctx->tmp, &ctx->masks, &ctx->row_cnt, &ctx->row_off,
+                      &ctx->cand, &ctx->cand_mask, &ctx->cand_mm, &ctx->feat, &ctx->hist, &ctx->table,
+                      &ctx->layer_consts, &ctx->counters, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best,
+                      &ctx->d1, &ctx->d2, &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->gau_all, &ctx->dog_all};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    if (ctx->h_feat.p) hipHostFree(ctx->h_feat.p);
+    if (ctx->h_hist.p) hipHostFree(ctx->h_hist.p);
+    if (ctx->h_counters) hipHostFree(ctx->h_counters);
+    for (auto& e : ctx->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : ctx->free_events) hipEventDestroy(e);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    delete ctx;
+    return SIFT_HIP_OK;
+}
+
+void sift_hip_default_params(sift_hip_params* p) {
+    if (!p) return;
+    p->octaves = 0;
+    p->intvls = 3;       // SIFT_INTVLS
+    p->sigma0 = 1.6f;    // SIFT_GauSigma
+    p->dx_thr = 0.03f;   // SIFT_Dx
+    p->subpixel = 0;
+    p->blur_mode = 0;
+    p->contr_thr = 0.05f;  // SIFT_CONTR_THR
+    p->reserved = 0;
+}
+
+const char* sift_hip_strerror(int s) {
+    switch (s) {
+        case SIFT_HIP_OK: return "ok";
+        case SIFT_HIP_ERR_ARG: return "invalid argument";
+        case SIFT_HIP_ERR_NOSPC: return "output capacity too small";
+        case SIFT_HIP_ERR_HIP: return "HIP runtime error";
+        case SIFT_HIP_ERR_NOMEM: return "out of device memory";
+        case SIFT_HIP_ERR_SAME: return "input and output are the same buffer";
+        case SIFT_HIP_ERR_NODEVICE: return "no usable gfx950 device";
+        case SIFT_HIP_ERR_LIMIT: return "internal limit exceeded";
+        default: return "unknown status";
+    }
+}
+
+const char* sift_hip_last_error(const sift_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+void* sift_hip_stream(sift_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int sift_hip_synchronize(sift_hip_ctx* ctx) {
+    if (bad_ctx(ctx)) return SIFT_HIP_ERR_ARG;
+    return hip_ok(ctx, hipStreamSynchronize(ctx->stream), "synchronize") ? SIFT_HIP_OK : SIFT_HIP_ERR_HIP;
+}
+
+int sift_hip_pyramid_octaves(int w, int h) {
+    if (w <= 0 || h <= 0) return SIFT_HIP_ERR_ARG;
+    return pyramid_octaves((size_t)w, (size_t)h);
+}
+
+int sift_hip_gau_matrix(float p, int mat_len, float* taps, int cap) {
+    if (!taps || mat_len < 0 || !(p > 0.f)) return SIFT_HIP_ERR_ARG;
+    std::vector<float> g = gau_matrix(p, (size_t)mat_len);
+    if ((int)g.size() > cap) return -(int)g.size();
+    std::memcpy(taps, g.data(), g.size() * sizeof(float));
+    return (int)g.size();
+}
+
+int sift_hip_extract_dev(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params* params,
+                         sift_hip_feat* out, int cap, int* n, float* hist) {
+    if (bad_ctx(ctx) || !d_gray || w < 2 || h < 2 || !n || cap < 0 || (cap > 0 && !out)) return SIFT_HIP_ERR_ARG;
+    *n = 0;
+    return extract_dev_impl(ctx, d_gray, w, h, params, out, cap, n, hist);
+}
+
+int sift_hip_extract(sift_hip_ctx* ctx, const float* img, int w, int h, int channels, const sift_hip_params* params,
+                     sift_hip_feat* out, int cap, int* n, float* hist) {
+    if (bad_ctx(ctx) || !img || w < 2 || h < 2 || !n || cap < 0 || (cap > 0 && !out)) return SIFT_HIP_ERR_ARG;
+    if (channels != 1 && channels != 3) return SIFT_HIP_ERR_ARG;
+    *n = 0;
+    const size_t px = (size_t)w * h;
+    int rc;
+    if ((rc = ensure(ctx, ctx->in_img, px * 4))) return rc;
+    if (channels == 3) {
+        if ((rc = ensure(ctx, ctx->in_rgb, px * 12))) return rc;
+        if (!hip_ok(ctx, hipMemcpyAsync(ctx->in_rgb.p, img, px * 12, hipMemcpyHostToDevice, ctx->stream), "upload"))
+            return SIFT_HIP_ERR_HIP;
+        launch_gray(ctx, (const float*)ctx->in_rgb.p, (float*)ctx->in_img.p, px);
+    } else {
+        if (!hip_ok(ctx, hipMemcpyAsync(ctx->in_img.p, img, px * 4, hipMemcpyHostToDevice, ctx->stream), "upload"))
+            return SIFT_HIP_ERR_HIP;
+    }
+    return extract_dev_impl(ctx, (const float*)ctx->in_img.p, w, h, params, out, cap, n, hist);
+}
+
+int sift_hip_extract_batch_dev(sift_hip_ctx* ctx, const float* d_frames, int w, int h, int nframes,
+                               const sift_hip_params* params, sift_hip_feat* out, int cap, int* n) {
+    if (bad_ctx(ctx) || !d_frames || w < 2 || h < 2 || nframes < 0 || !n || cap < 0 || (cap > 0 && !out))
+        return SIFT_HIP_ERR_ARG;
+    int worst = SIFT_HIP_OK;
+    for (int f = 0; f < nframes; f++) {
+        n[f] = 0;
+        int rc = extract_dev_impl(ctx, d_frames + (size_t)f * w * h, w, h, params, out + (size_t)f * cap, cap, &n[f],
+                                  nullptr);
+        if (rc == SIFT_HIP_ERR_NOSPC) worst = rc;
+        else if (rc) return rc;
+    }
+    return worst;
+}
+
+int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h, int nframes,
+                           const sift_hip_params* params, sift_hip_feat* out, int cap, int* n) {
+    if (bad_ctx(ctx) || !frames || w < 2 || h < 2 || nframes < 0 || !n || cap < 0 || (cap > 0 && !out))
+        return SIFT_HIP_ERR_ARG;
+    const size_t px = (size_t)w * h;
+    int rc;
+    if ((rc = ensure(ctx, ctx->in_img, px * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->frame2, px * 4))) return rc;
+    float* slot[2] = {(float*)ctx->in_img.p, (float*)ctx->frame2.p};
+    hipEvent_t up[2], done[2];
+    for (int i = 0; i < 2; i++) { hipEventCreateWithFlags(&up[i], hipEventDisableTiming); hipEventCreateWithFlags(&done[i], hipEventDisableTiming); }
+    int worst = SIFT_HIP_OK;
+    // frame f+1 is uploaded on the copy stream while frame f's kernels run
+    if (nframes > 0) {
+        hipMemcpyAsync(slot[0], frames, px * 4, hipMemcpyHostToDevice, ctx->copy_stream);
+        hipEventRecord(up[0], ctx->copy_stream);
+    }
+    for (int f = 0; f < nframes && worst != SIFT_HIP_ERR_HIP; f++) {
+        const int s = f & 1;
+        if (f + 1 < nframes) {
+            if (f >= 1) hipStreamWaitEvent(ctx->copy_stream, done[s ^ 1], 0);  // slot free again
+            hipMemcpyAsync(slot[s ^ 1], frames + (size_t)(f + 1) * px, px * 4, hipMemcpyHostToDevice, ctx->copy_stream);
+            hipEventRecord(up[s ^ 1], ctx->copy_stream);
+        }
+        hipStreamWaitEvent(ctx->stream, up[s], 0);
+        n[f] = 0;
+        rc = extract_dev_impl(ctx, slot[s], w, h, params, out + (size_t)f * cap, cap, &n[f], nullptr);
+        hipEventRecord(done[s], ctx->stream);
+        if (rc == SIFT_HIP_ERR_NOSPC) worst = rc;
+        else if (rc) { worst = rc; break; }
+    }
+    hipStreamSynchronize(ctx->copy_stream);
+    hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++) { hipEventDestroy(up[i]); hipEventDestroy(done[i]); }
+    return worst;
+}
+
+int sift_hip_gau_blur(sift_hip_ctx* ctx, const float* in, float* out, int w, int h, float p, int blur_mode) {
+    if (bad_ctx(ctx) || !in || !out || w < 1 || h < 1 || !(p > 0.f)) return SIFT_HIP_ERR_ARG;
+    if (in == out) return SIFT_HIP_ERR_SAME;
+    const size_t px = (size_t)w * h;
+    std::vector<float> g = gau_matrix(p, 0);
+    int rc;
+    if ((rc = ensure(ctx, ctx->io_a, px * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->io_b, px * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->tmp, px * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->best, g.size() * 4 + 64))) return rc;  // scratch for this call's taps
+    hipMemcpyAsync(ctx->best.p, g.data(), g.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(ctx->io_a.p, in, px * 4, hipMemcpyHostToDevice, ctx->stream);
+    launch_blur(ctx, (const float*)ctx->io_a.p, (float*)ctx->tmp.p, (float*)ctx->io_b.p, w, h,
+                (const float*)ctx->best.p, (int)g.size(), blur_mode, nullptr, nullptr);
+    hipMemcpyAsync(out, ctx->io_b.p, px * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "gau_blur")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "gau_blur");
+}
+
+int sift_hip_first(sift_hip_ctx* ctx, const float* in, int w, int h, float ratio, float* out) {
+    if (bad_ctx(ctx) || !in || !out || w < 1 || h < 1 || !(ratio > 0.f)) return SIFT_HIP_ERR_ARG;
+    const int nh = static_cast<int>(std::floor((size_t)h * ratio));
+    const int nw = static_cast<int>(std::floor((size_t)w * ratio));
+    if (nw < 1 || nh < 1) return SIFT_HIP_ERR_ARG;
+    int rc;
+    if ((rc = ensure(ctx, ctx->io_a, (size_t)w * h * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->io_b, (size_t)nw * nh * 4))) return rc;
+    hipMemcpyAsync(ctx->io_a.p, in, (size_t)w * h * 4, hipMemcpyHostToDevice, ctx->stream);
+    launch_first(ctx, (const float*)ctx->io_a.p, w, h, ratio, (float*)ctx->io_b.p, nw, nh);
+    hipMemcpyAsync(out, ctx->io_b.p, (size_t)nw * nh * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "first")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "first");
+}
+
+int sift_hip_convert_gray(sift_hip_ctx* ctx, const float* rgb, int n, float* gray) {
+    if (bad_ctx(ctx) || !rgb || !gray || n < 1) return SIFT_HIP_ERR_ARG;
+    int rc;
+    if ((rc = ensure(ctx, ctx->io_a, (size_t)n * 12))) return rc;
+    if ((rc = ensure(ctx, ctx->io_b, (size_t)n * 4))) return rc;
+    hipMemcpyAsync(ctx->io_a.p, rgb, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream);
+    launch_gray(ctx, (const float*)ctx->io_a.p, (float*)ctx->io_b.p, (size_t)n);
+    hipMemcpyAsync(gray, ctx->io_b.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "convert_gray")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "convert_gray");
+}
+
+int sift_hip_octave_levels(sift_hip_ctx* ctx, const float* gray, int w, int h, const sift_hip_params* params,
+                           int octave, float* gau, float* dog, int* ow, int* oh) {
+    if (bad_ctx(ctx) || !gray || w < 2 || h < 2 || octave < 0 || !ow || !oh) return SIFT_HIP_ERR_ARG;
+    sift_hip_params prm;
+    if (params) prm = *params; else sift_hip_default_params(&prm);
+    if (prm.intvls < 1 || prm.intvls > 8) return SIFT_HIP_ERR_ARG;
+    if (prm.octaves > 0 && prm.octaves <= octave) prm.octaves = octave + 1;
+    int rc = build_plan(ctx, w, h, prm);
+    if (rc) return rc;
+    if (octave >= (int)ctx->plan.oct.size()) return SIFT_HIP_ERR_ARG;
+    const OctavePlan& oc = ctx->plan.oct[octave];
+    const size_t PX = (size_t)oc.W * oc.H;
+    if ((rc = ensure(ctx, ctx->in_img, (size_t)w * h * 4))) return rc;
+    hipMemcpyAsync(ctx->in_img.p, gray, (size_t)w * h * 4, hipMemcpyHostToDevice, ctx->stream);
+    if ((rc = run_octave_pyramid(ctx, (const float*)ctx->in_img.p, octave))) return rc;
+    const int pyWidth = prm.intvls + 3;
+    if (gau) hipMemcpyAsync(gau, ctx->gau_all.p, PX * 4 * pyWidth, hipMemcpyDeviceToHost, ctx->stream);
+    if (dog) hipMemcpyAsync(dog, ctx->dog_all.p, PX * 4 * (pyWidth - 1), hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "octave_levels")) return SIFT_HIP_ERR_HIP;
+    *ow = oc.W;
+    *oh = oc.H;
+    return check_async(ctx, "octave_levels");
+}
+
+int sift_hip_match_u8_dev(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
+                          int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
+    if (bad_ctx(ctx) || nq < 0 || nr < 0 || (nq > 0 && (!d_q || !d_best)) || (nr > 0 && !d_r)) return SIFT_HIP_ERR_ARG;
+    if (ratio_form != 0 && ratio_form != 1) return SIFT_HIP_ERR_ARG;
+    if (nq == 0) return SIFT_HIP_OK;
+    int rc = run_match(ctx, d_q, nq, d_r, nr, ratio, ratio_form, d_best, d_d1, d_d2);
+    if (rc) return rc;
+    return check_async(ctx, "match launch");
+}
+
+int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t* r, int nr, float ratio,
+                      int ratio_form, int32_t* best, int32_t* d1, int32_t* d2) {
+    if (bad_ctx(ctx) || nq < 0 || nr < 0 || (nq > 0 && (!q || !best)) || (nr > 0 && !r)) return SIFT_HIP_ERR_ARG;
+    if (ratio_form != 0 && ratio_form != 1) return SIFT_HIP_ERR_ARG;
+    if (nq == 0) return SIFT_HIP_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->io_a, (size_t)nq * 128))) return rc;
+    if ((rc = ensure(ctx, ctx->io_b, (size_t)std::max(nr, 1) * 128))) return rc;
+    if ((rc = ensure(ctx, ctx->best, (size_t)nq * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d1, (size_t)nq * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d2, (size_t)nq * 4))) return rc;
+    hipMemcpyAsync(ctx->io_a.p, q, (size_t)nq * 128, hipMemcpyHostToDevice, ctx->stream);
+    if (nr > 0) hipMemcpyAsync(ctx->io_b.p, r, (size_t)nr * 128, hipMemcpyHostToDevice, ctx->stream);
+    rc = run_match(ctx, (const uint8_t*)ctx->io_a.p, nq, (const uint8_t*)ctx->io_b.p, nr, ratio, ratio_form,
+                   (int32_t*)ctx->best.p, (int32_t*)ctx->d1.p, (int32_t*)ctx->d2.p);
+    if (rc) return rc;
+    hipMemcpyAsync(best, ctx->best.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (d1) hipMemcpyAsync(d1, ctx->d1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (d2) hipMemcpyAsync(d2, ctx->d2.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "match")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "match");
+}
+
+int sift_hip_profile(sift_hip_ctx* ctx, int enable) {
+    if (!ctx) return SIFT_HIP_ERR_ARG;
+    ctx->profiling = enable != 0;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset) {
+    if (bad_ctx(ctx)) return SIFT_HIP_ERR_ARG;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "profile_read")) return SIFT_HIP_ERR_HIP;
+    for (auto& e : ctx->events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) {
+            ctx->prof_ms[e.cls] += t;
+            ctx->prof_n[e.cls] += 1;
+        }
+        ctx->free_events.push_back(e.a);
+        ctx->free_events.push_back(e.b);
+    }
+    ctx->events.clear();
+    for (int k = 0; k < SIFT_HIP_K_COUNT; k++) {
+        if (ms) ms[k] = ctx->prof_ms[k];
+        if (launches) launches[k] = ctx->prof_n[k];
+        if (reset) { ctx->prof_ms[k] = 0.f; ctx->prof_n[k] = 0; }
+    }
+    return SIFT_HIP_OK;
+}
+
+const char* sift_hip_kernel_class_name(int k) {
+    static const char* names[SIFT_HIP_K_COUNT] = {"resample", "blur_row", "blur_col", "detect", "compact",
+                                                  "orient",   "emit",     "descr",    "match",  "gray"};
+    return (k >= 0 && k < SIFT_HIP_K_COUNT) ? names[k] : "?";
+}
+
+}  // extern "C"

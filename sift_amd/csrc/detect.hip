@@ -1,0 +1,324 @@
+// Keypoint detection for one octave on gfx950:
+//   detect_rows   3x3x3 extremum + contrast + edge test, one workgroup per image
+//                 row of one DoG layer; wavefront ballots become 64-pixel mask words
+//   scan_rows     exclusive prefix sum of the per-row counts (one workgroup)
+//   expand_rows   mask words -> ordered candidate list (wave prefix sums)
+//   orient        36-bin orientation histogram, one wavefront per candidate
+//   emit          candidates x firing bins -> feature records, in reference order
+//
+// The candidate order (layer, row, column) and the feature order (candidate,
+// bin) reproduce the append order of the reference's scan (Sift.cpp:173-200,
+// :285-293), so the output array equals its linked list copied out (:207-224).
+#include "internal.h"
+
+namespace sifthip {
+
+// ---- findMaxMin (Sift.cpp:86-104) + harris_corner (Sift.cpp:105-129) -------------
+__device__ __forceinline__ bool is_keypoint(const float* __restrict__ dprev, const float* __restrict__ dcur,
+                                            const float* __restrict__ dnext, int W, int y, int x, float thr,
+                                            float rad) {
+    const size_t c = (size_t)y * W + x;
+    const float v = dcur[c];
+    if (!(fabsf(v) > thr)) return false;
+    const float* lay[3] = {dprev, dcur, dnext};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int j = -1; j <= 1; j++) {
+#pragma unroll
+            for (int i = -1; i <= 1; i++) {
+                const float nb = lay[k][c + (ptrdiff_t)j * W + i];
+                if (v > 0.f && v < nb) return false;
+                if (v < 0.f && v > nb) return false;
+            }
+        }
+    }
+    // edge test; the "r" of the reference call is the histogram radius
+    const float thre = ((rad + 1.f) * (rad + 1.f)) / rad;
+    const float l = dcur[c - 1], rr = dcur[c + 1], u = dcur[c - W], d = dcur[c + W];
+    const float Dxx = 2.f * v - l - rr;
+    const float Dyy = 2.f * v - u - d;
+    float Dxy = dcur[c + W + 1] + dcur[c - W - 1] - dcur[c - W + 1] - dcur[c + W - 1];
+    Dxy /= 4.f;
+    const float Tr = Dxx + Dyy;
+    const float Det = Dxx * Dyy - Dxy * Dxy;
+    const float val = (Tr * Tr / Det);
+    return val < thre;
+}
+
+// grid.x = intvls * H rows.  Writes every mask word of the row (zeros included)
+// and the row's candidate count.
+__global__ __launch_bounds__(256) void detect_rows_kernel(const float* __restrict__ dog, size_t PX, int W, int H,
+                                                          const LayerConsts* __restrict__ lc, float thr, int WW,
+                                                          unsigned long long* __restrict__ masks,
+                                                          int* __restrict__ row_cnt) {
+    __shared__ int s_cnt[4];
+    const int row = blockIdx.x;
+    const int li = row / H;  // layer index 0..intvls-1  (DoG layer li+1)
+    const int y = row - li * H;
+    const int rad = lc[li].radius;
+    const float* dprev = dog + (size_t)li * PX;
+    const float* dcur = dprev + PX;
+    const float* dnext = dcur + PX;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // scan bounds of Sift.cpp:178-179: r+1 <= y < H-r-1, r+1 <= x < W-r-1
+    const bool row_ok = (H >= 2 * rad + 3) && (W >= 2 * rad + 3) && y >= rad + 1 && y < H - rad - 1;
+    int cnt = 0;
+    for (int xb = 0; xb < WW * 64; xb += 256) {
+        const int x = xb + threadIdx.x;
+        bool hit = false;
+        if (row_ok && x >= rad + 1 && x < W - rad - 1) hit = is_keypoint(dprev, dcur, dnext, W, y, x, thr, (float)rad);
+        const unsigned long long m = __ballot(hit);
+        const int word = (xb >> 6) + wave;
+        if (lane == 0 && word < WW) masks[(size_t)row * WW + word] = m;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) row_cnt[row] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// Exclusive scan of n ints by one 1024-thread workgroup; total -> counters.
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* s_warp, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_warp[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        int w = (lane < 16) ? s_warp[lane] : 0;
+        int winc = w;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int t = __shfl_up(winc, o);
+            if (lane >= o) winc += t;
+        }
+        if (lane < 16) s_warp[16 + lane] = winc - w;  // exclusive wave offsets
+        if (lane == 15) s_warp[32] = winc;
+    }
+    __syncthreads();
+    total = s_warp[32];
+    const int res = s_warp[16 + wave] + inc - v;
+    __syncthreads();
+    return res;
+}
+
+__global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ row_cnt, int* __restrict__ row_off,
+                                                         int nrows, int cand_cap, int* __restrict__ counters) {
+    __shared__ int s_warp[40];
+    int running = 0;
+    for (int b = 0; b < nrows; b += 1024) {
+        const int i = b + threadIdx.x;
+        const int v = (i < nrows) ? row_cnt[i] : 0;
+        int total;
+        const int ex = block_excl_scan_1024(v, s_warp, total);
+        if (i < nrows) row_off[i] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        counters[CNT_NCAND_TOTAL] = running;
+        counters[CNT_NCAND] = min(running, cand_cap);
+        if (running > cand_cap) counters[CNT_CAND_OVERFLOW] = max(counters[CNT_CAND_OVERFLOW], running);
+    }
+}
+
+// One wavefront per row: turn its mask words into candidates at row_off[row]...
+__global__ __launch_bounds__(64) void expand_rows_kernel(const unsigned long long* __restrict__ masks,
+                                                         const int* __restrict__ row_cnt,
+                                                         const int* __restrict__ row_off, int H, int WW,
+                                                         Cand* __restrict__ cand, int cand_cap) {
+    const int row = blockIdx.x;
+    if (row_cnt[row] == 0) return;
+    const int lane = threadIdx.x;
+    const int li = row / H;
+    const int y = row - li * H;
+    int running = row_off[row];
+    for (int wb = 0; wb < WW; wb += 64) {
+        const int word = wb + lane;
+        unsigned long long m = (word < WW) ? masks[(size_t)row * WW + word] : 0ull;
+        const int c = __popcll(m);
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        int pos = running + inc - c;
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < cand_cap) cand[pos] = Cand{word * 64 + bit, y, li + 1};
+            pos++;
+        }
+        running += __shfl(inc, 63);
+    }
+}
+
+// ---- fastAtan2f, Imgraw.cpp:29-52 (degrees) ------------------------------------
+__device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
+    const float k = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * k;
+    const float p3 = -0.3258083974640975f * k;
+    const float p5 = 0.1555786518463281f * k;
+    const float p7 = -0.04432655554792128f * k;
+    const float eps = (float)2.2204460492503131e-016;
+    const float ax = fabsf(dx), ay = fabsf(dy);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (dx < 0) a = 180.f - a;
+    if (dy < 0) a = 360.f - a;
+    return a;
+}
+
+// ---- Sift::getHistogramMS, Sift.cpp:250-295 ---------------------------------------
+// One wavefront per candidate.  The reference adds the weighted magnitudes into
+// the 36 bins one window pixel after another (row-major); float addition is not
+// associative and the ">= 0.8 * max" test decides how many features a keypoint
+// becomes, so the order is kept: the window is evaluated in parallel into LDS in
+// chunks, then lane b walks the chunk in order and adds the entries of bin b.
+constexpr int ORI_CH = 2048;
+
+__global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ dog, size_t PX, int W,
+                                                    const LayerConsts* __restrict__ lc,
+                                                    const float* __restrict__ table, const Cand* __restrict__ cand,
+                                                    const int* __restrict__ counters,
+                                                    unsigned long long* __restrict__ cmask, float* __restrict__ cmm) {
+    __shared__ float s_val[ORI_CH];
+    __shared__ unsigned char s_bin[ORI_CH];
+    const int lane = threadIdx.x;
+    const int ncand = counters[CNT_NCAND];
+    for (int ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
+        const Cand cd = cand[ci];
+        const LayerConsts L = lc[cd.layer - 1];
+        const int r = L.radius;
+        const int n = 2 * r + 1;
+        const int total = n * n;
+        const float* img = dog + (size_t)cd.layer * PX;
+        const float* g = table + L.wts_off;
+        float sum = 0.f;
+        for (int e0 = 0; e0 < total; e0 += ORI_CH) {
+            const int cnt = min(ORI_CH, total - e0);
+            for (int e = lane; e < cnt; e += 64) {
+                const int idx = e0 + e;
+                const int jj = idx / n;
+                const int ii = idx - jj * n;
+                const size_t p = (size_t)(cd.y - r + jj) * W + (cd.x - r + ii);
+                const float dx = img[p + 1] - img[p - 1];
+                const float dy = img[p + W] - img[p - W];
+                float mag = sqrtf(dx * dx + dy * dy);
+                const float th = fast_atan2f_deg(dy, dx);
+                mag = mag * g[ii];
+                mag = mag * g[jj];
+                s_val[e] = mag;
+                s_bin[e] = (unsigned char)(int)((double)th / 10.0);  // 36 == "one past the end": dropped
+            }
+            __syncthreads();
+            if (lane < 36) {
+                for (int e = 0; e < cnt; e++) sum += (s_bin[e] == lane) ? s_val[e] : 0.f;
+            }
+            __syncthreads();
+        }
+        float mx = (lane < 36) ? sum : 0.f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const bool fire = (lane < 36) && ((double)sum >= (double)mx * 0.8);
+        const unsigned long long m = __ballot(fire);
+        if (lane == 0) cmask[ci] = m;
+        if (lane < 36) cmm[(size_t)ci * 36 + lane] = sum;
+    }
+}
+
+// ---- FeatAppend order (Sift.cpp:229-249, :285-293) ------------------------------
+// One workgroup scans the per-candidate bin counts and writes the feature
+// records behind the features of earlier octaves.
+__global__ __launch_bounds__(1024) void emit_kernel(const Cand* __restrict__ cand,
+                                                    const unsigned long long* __restrict__ cmask,
+                                                    const float* __restrict__ cmm, const LayerConsts* __restrict__ lc,
+                                                    float curr_size, sift_hip_feat* __restrict__ feat, int feat_cap,
+                                                    int* __restrict__ counters) {
+    __shared__ int s_warp[40];
+    const int ncand = counters[CNT_NCAND];
+    const int begin = counters[CNT_FEAT_TOTAL];
+    int running = begin;
+    for (int b = 0; b < ncand; b += 1024) {
+        const int i = b + threadIdx.x;
+        unsigned long long m = (i < ncand) ? cmask[i] : 0ull;
+        const int v = __popcll(m);
+        int total;
+        const int ex = block_excl_scan_1024(v, s_warp, total);
+        if (v) {
+            const Cand cd = cand[i];
+            const LayerConsts L = lc[cd.layer - 1];
+            int pos = running + ex;
+            while (m) {
+                const int bin = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (pos < feat_cap) {
+                    sift_hip_feat* f = feat + pos;
+                    f->size = curr_size;
+                    f->kai = cd.layer;
+                    f->sigmaOCT = L.sigma_oct;
+                    f->x = cd.x;
+                    f->y = cd.y;
+                    f->mm = cmm[(size_t)i * 36 + bin];
+                    f->sita = bin * 10;
+                }
+                pos++;
+            }
+        }
+        running += total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[CNT_OCT_BEGIN] = begin;
+        counters[CNT_FEAT_TOTAL] = running;
+    }
+}
+
+void launch_detect(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
+                   float thr, int cand_cap) {
+    const int WW = (W + 63) / 64;
+    const int nrows = intvls * H;
+    {
+        ProfScope ps(ctx, SIFT_HIP_K_DETECT);
+        hipLaunchKernelGGL(detect_rows_kernel, dim3(nrows), dim3(256), 0, ctx->stream, dog, PX, W, H, d_lc, thr, WW,
+                           (unsigned long long*)ctx->masks.p, (int*)ctx->row_cnt.p);
+    }
+    {
+        ProfScope ps(ctx, SIFT_HIP_K_COMPACT);
+        hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->row_cnt.p,
+                           (int*)ctx->row_off.p, nrows, cand_cap, (int*)ctx->counters.p);
+        hipLaunchKernelGGL(expand_rows_kernel, dim3(nrows), dim3(64), 0, ctx->stream,
+                           (const unsigned long long*)ctx->masks.p, (const int*)ctx->row_cnt.p,
+                           (const int*)ctx->row_off.p, H, WW, (Cand*)ctx->cand.p, cand_cap);
+    }
+}
+
+void launch_orient(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, const LayerConsts* d_lc,
+                   const float* d_table) {
+    ProfScope ps(ctx, SIFT_HIP_K_ORIENT);
+    hipLaunchKernelGGL(orient_kernel, dim3(256 * 12), dim3(64), 0, ctx->stream, dog, PX, W, d_lc, d_table,
+                       (const Cand*)ctx->cand.p, (const int*)ctx->counters.p, (unsigned long long*)ctx->cand_mask.p,
+                       (float*)ctx->cand_mm.p);
+}
+
+void launch_emit(sift_hip_ctx* ctx, float curr_size, const LayerConsts* d_lc, int feat_cap) {
+    ProfScope ps(ctx, SIFT_HIP_K_EMIT);
+    hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const Cand*)ctx->cand.p,
+                       (const unsigned long long*)ctx->cand_mask.p, (const float*)ctx->cand_mm.p, d_lc, curr_size,
+                       (sift_hip_feat*)ctx->feat.p, feat_cap, (int*)ctx->counters.p);
+}
+
+}  // namespace sifthip

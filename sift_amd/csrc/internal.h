@@ -1,0 +1,122 @@
+// Internal declarations shared by the HIP translation units of libsift_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sift_hip.h"
+
+namespace sifthip {
+
+// ---- device-side records ------------------------------------------------------
+struct Cand {  // an extremum that passed the contrast and edge tests
+    int32_t x, y, layer;
+};
+
+// Slots of the per-context device counter block.
+enum Counter {
+    CNT_NCAND = 0,        // candidates stored for the current octave (<= capacity)
+    CNT_NCAND_TOTAL = 1,  // candidates found for the current octave
+    CNT_FEAT_TOTAL = 2,   // features found so far (all octaves, may exceed capacity)
+    CNT_OCT_BEGIN = 3,    // CNT_FEAT_TOTAL before the current octave
+    CNT_CAND_OVERFLOW = 4,
+    CNT_SLOTS = 8
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-183)
+    float curr_size;       // 2, 1, 0.5 ...
+    float coef;            // 1, 2, 4 ...
+    int W, H;
+    std::vector<float> sigma;      // per Gaussian level
+    std::vector<int> tap_off;      // offset of each level's taps in the tap table
+    std::vector<int> tap_len;
+    std::vector<int> radius;       // per DoG layer 1..intvls: window radius r (Sift.cpp:177)
+    std::vector<float> curr_sigma; // per layer: currSigma (Sift.cpp:183)
+    std::vector<int> wts_off;      // per layer: offset of the orientation weights
+};
+
+struct Plan {
+    int w = 0, h = 0;
+    sift_hip_params prm{};
+    std::vector<OctavePlan> oct;
+    std::vector<float> table;  // taps and orientation weights, concatenated
+    bool valid = false;
+};
+
+}  // namespace sifthip
+
+struct sift_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;
+    std::string last_error;
+
+    sifthip::Plan plan;
+    // device workspace (grown on demand, never shrunk)
+    sifthip::DevBuf in_img, in_rgb, base, tmp, masks, row_cnt, row_off, cand, cand_mask, cand_mm, feat, hist,
+        table, layer_consts, counters, qi8, ri8, qnorm, rconst, best, d1, d2, io_a, io_b, frame2,
+        gau_all, dog_all;  // all Gaussian / DoG levels of the current octave, level-major
+    int cand_cap = 0;
+    // pinned host staging
+    int32_t* h_counters = nullptr;
+    sifthip::DevBuf h_feat, h_hist;
+
+    // profiling
+    bool profiling = false;
+    struct Ev { int cls; hipEvent_t a, b; };
+    std::vector<Ev> events;
+    std::vector<hipEvent_t> free_events;
+    float prof_ms[SIFT_HIP_K_COUNT] = {0};
+    int prof_n[SIFT_HIP_K_COUNT] = {0};
+};
+
+namespace sifthip {
+
+// Returns false and records the message in ctx->last_error on failure.
+bool hip_ok(sift_hip_ctx* ctx, hipError_t e, const char* what);
+int ensure(sift_hip_ctx* ctx, DevBuf& b, size_t bytes);
+int ensure_pinned(sift_hip_ctx* ctx, DevBuf& b, size_t bytes);
+void prof_begin(sift_hip_ctx* ctx, int cls);
+void prof_end(sift_hip_ctx* ctx);
+
+struct ProfScope {
+    sift_hip_ctx* c;
+    ProfScope(sift_hip_ctx* ctx, int cls) : c(ctx) { if (c->profiling) prof_begin(c, cls); }
+    ~ProfScope() { if (c->profiling) prof_end(c); }
+};
+
+// ---- launchers (defined next to their kernels) --------------------------------
+// pyramid.hip
+void launch_gray(sift_hip_ctx* ctx, const float* rgb, float* gray, size_t n);
+void launch_first(sift_hip_ctx* ctx, const float* src, int w, int h, float ratio, float* dst, int nw, int nh);
+// One separable blur: src -> (tmp) -> dst; if dog != nullptr also dog = prev - dst.
+void launch_blur(sift_hip_ctx* ctx, const float* src, float* tmp, float* dst, int W, int H, const float* d_taps,
+                 int K, int blur_mode, const float* prev, float* dog);
+// detect.hip
+struct LayerConsts {  // per DoG layer 1..intvls of one octave
+    int32_t radius;       // histogram window radius r (Sift.cpp:177)
+    int32_t wts_off;      // offset of the 2r+1 orientation weights in the table (floats)
+    float curr_sigma;     // currSigma (Sift.cpp:183)
+    float sigma_oct;      // (float)(int)curr_sigma, what FeatAppend stores
+};
+// dog / gau: level-major images of the current octave, PX pixels per level.
+void launch_detect(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
+                   float thr, int cand_cap);
+void launch_orient(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, const LayerConsts* d_lc,
+                   const float* d_table);
+void launch_emit(sift_hip_ctx* ctx, float curr_size, const LayerConsts* d_lc, int feat_cap);
+// descriptor.hip
+void launch_descr(sift_hip_ctx* ctx, const float* gau, size_t PX, int W, int H, const float* d_cs, int feat_cap,
+                  float* d_hist);
+// match.hip
+int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
+              int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
+
+}  // namespace sifthip

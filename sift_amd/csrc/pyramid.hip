@@ -1,0 +1,316 @@
+// Scale-space kernels for gfx950: gray conversion, bilinear octave resample,
+// separable Gaussian blur (row pass, column pass with fused DoG write).
+//
+// Numerics follow the reference exactly in blur_mode 0: every tap is a float
+// product rounded to float, accumulated in double in ascending tap order, and the
+// sum is rounded to float once per pass (imglib/imglib.cpp:85-117).  That makes
+// the blur VALU-bound (one v_mul_f32, one v_cvt_f64_f32, one v_add_f64 per tap)
+// rather than HBM-bound; the kernels therefore never recompute a tap: rows and
+// columns run as two launches with the intermediate image in HBM / Infinity Cache.
+// Each thread produces P consecutive outputs ALONG the filter direction and keeps
+// a sliding window of P inputs in registers, so a tap step costs one LDS read and
+// one scalar tap load for P multiply-accumulates.
+#include "internal.h"
+
+namespace sifthip {
+
+// ---- ImgRaw::ConverGray, Imgraw.cpp:257-269 --------------------------------------
+__global__ __launch_bounds__(256) void gray_kernel(const float* __restrict__ rgb, float* __restrict__ gray, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float R = rgb[i * 3 + 0], G = rgb[i * 3 + 1], B = rgb[i * 3 + 2];
+    // double products and sums, left to right, one rounding to float at the end
+    double v = (double)R * 0.299;
+    v = v + (double)G * 0.587;
+    v = v + (double)B * 0.114;
+    gray[i] = (float)v;
+}
+
+void launch_gray(sift_hip_ctx* ctx, const float* rgb, float* gray, size_t n) {
+    ProfScope ps(ctx, SIFT_HIP_K_GRAY);
+    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rgb, gray, n);
+}
+
+// ---- Scaling::first + Scaling::bilinear, imglib.cpp:203-252 ----------------------
+__global__ __launch_bounds__(256) void first_kernel(const float* __restrict__ src, int w, int h, float ratio,
+                                                    float* __restrict__ dst, int nw, int nh) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= nw || j >= nh) return;
+    float srcY, srcX;
+    if (ratio < 1) {
+        // ((j+0.5f)/Ratio) is a float quotient; the "- 0.5" is done in double
+        srcY = (float)((double)(((float)j + 0.5f) / ratio) - 0.5);
+        srcX = (float)((double)(((float)i + 0.5f) / ratio) - 0.5);
+    } else {
+        srcY = (float)j * ((float)h - 1.f) / ((float)nh - 1.f);
+        srcX = (float)i * ((float)w - 1.f) / ((float)nw - 1.f);
+    }
+    const float fx0 = floorf(srcX), fy0 = floorf(srcY);
+    int x0 = (int)fx0, x1 = (int)ceilf(srcX);
+    int y0 = (int)fy0, y1 = (int)ceilf(srcY);
+    const float dx1 = srcX - fx0;  // x - x0 with x0 converted back to float
+    const float dx2 = 1.f - dx1;
+    const float dy1 = srcY - fy0;
+    const float dy2 = 1.f - dy1;
+    // The reference indexes past the row/image when ceil() leaves it; clamp instead.
+    x1 = min(x1, w - 1);
+    y1 = min(y1, h - 1);
+    const float A = src[(size_t)y0 * w + x0];
+    const float B = src[(size_t)y0 * w + x1];
+    const float C = src[(size_t)y1 * w + x0];
+    const float D = src[(size_t)y1 * w + x1];
+    const float AB = A * dx2 + B * dx1;
+    const float CD = C * dx2 + D * dx1;
+    dst[(size_t)j * nw + i] = AB * dy2 + CD * dy1;
+}
+
+void launch_first(sift_hip_ctx* ctx, const float* src, int w, int h, float ratio, float* dst, int nw, int nh) {
+    ProfScope ps(ctx, SIFT_HIP_K_RESAMPLE);
+    dim3 grid((nw + 63) / 64, (nh + 3) / 4);
+    hipLaunchKernelGGL(first_kernel, grid, dim3(256), 0, ctx->stream, src, w, h, ratio, dst, nw, nh);
+}
+
+// ---- separable blur ----------------------------------------------------------------
+constexpr int P = 8;  // outputs per thread along the filter direction
+
+template <typename ACC>
+__device__ __forceinline__ void mac(ACC& acc, float a, float g);
+template <>
+__device__ __forceinline__ void mac<double>(double& acc, float a, float g) {
+    const float prod = a * g;  // rounded to float first, as `img[..] * gau_mat[k]` is
+    acc += (double)prod;
+}
+template <>
+__device__ __forceinline__ void mac<float>(float& acc, float a, float g) {
+    acc = fmaf(a, g, acc);
+}
+
+// LDS index with one pad word per 8 so that lanes 8 floats apart hit distinct banks.
+__device__ __forceinline__ int padx(int i) { return i + (i >> 3); }
+
+// Row pass: one wave per 512-pixel run of one row.  LDS holds the run plus halo.
+template <typename ACC>
+__global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
+                                                      int H, const float* __restrict__ taps, int K) {
+    extern __shared__ float s[];
+    const int lane = threadIdx.x;
+    const int r = K >> 1;
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * (64 * P);
+    const int n_in = 64 * P + K - 1;
+    const float* row = in + (size_t)y * W;
+    for (int i = lane; i < n_in; i += 64) {
+        int gx = x0 + i - r;
+        gx = max(0, min(gx, W - 1));
+        s[padx(i)] = row[gx];
+    }
+    __syncthreads();
+    const int base = lane * P;
+    if (x0 + base >= W) return;
+    ACC acc[P];
+    float win[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        acc[p] = 0;
+        win[p] = s[padx(base + p)];
+    }
+    int k = 0;
+    for (; k + P <= K; k += P) {
+#pragma unroll
+        for (int u = 0; u < P; u++) {
+            const float g = taps[k + u];
+#pragma unroll
+            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+            win[u] = s[padx(base + k + u + P)];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < P; u++) {
+        if (k + u < K) {  // wave-uniform
+            const float g = taps[k + u];
+#pragma unroll
+            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+            win[u] = s[padx(base + k + u + P)];
+        }
+    }
+    float* o = out + (size_t)y * W + x0 + base;
+    if ((W & 3) == 0 && x0 + base + P <= W) {
+        float4 a = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+        float4 b = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
+        reinterpret_cast<float4*>(o)[0] = a;
+        reinterpret_cast<float4*>(o)[1] = b;
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            if (x0 + base + p < W) o[p] = (float)acc[p];
+    }
+}
+
+// Column pass: a 256-thread workgroup owns 64 columns x TH rows; LDS holds the
+// TH + K - 1 input rows.  Each wave takes P-row chunks.  With DOG the kernel also
+// writes dog = prev - out (Sift.cpp:161-168), prev being the previous level.
+template <typename ACC, bool DOG>
+__global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                       const float* __restrict__ prev, float* __restrict__ dog, int W,
+                                                       int H, const float* __restrict__ taps, int K, int TH) {
+    extern __shared__ float s[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = K >> 1;
+    const int x = blockIdx.x * 64 + lane;
+    const int xc = min(x, W - 1);
+    const int y0 = blockIdx.y * TH;
+    const int rows_in = TH + K - 1;
+    for (int i = wave; i < rows_in; i += 4) {
+        int gy = y0 + i - r;
+        gy = max(0, min(gy, H - 1));
+        s[i * 64 + lane] = in[(size_t)gy * W + xc];
+    }
+    __syncthreads();
+    for (int c = wave * P; c < TH; c += 4 * P) {
+        if (y0 + c >= H) break;  // wave-uniform
+        ACC acc[P];
+        float win[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            acc[p] = 0;
+            win[p] = s[(c + p) * 64 + lane];
+        }
+        int k = 0;
+        for (; k + P <= K; k += P) {
+#pragma unroll
+            for (int u = 0; u < P; u++) {
+                const float g = taps[k + u];
+#pragma unroll
+                for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+                win[u] = s[(c + k + u + P) * 64 + lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < P; u++) {
+            if (k + u < K) {
+                const float g = taps[k + u];
+#pragma unroll
+                for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+                win[u] = s[(c + k + u + P) * 64 + lane];
+            }
+        }
+        if (x < W) {
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const int y = y0 + c + p;
+                if (y < H) {
+                    const float v = (float)acc[p];
+                    const size_t idx = (size_t)y * W + x;
+                    out[idx] = v;
+                    if (DOG) dog[idx] = prev[idx] - v;
+                }
+            }
+        }
+    }
+}
+
+// Column pass for kernels too long for an LDS tile: the window slides over rows
+// read straight from global memory (L1/L2 serve the overlap between row chunks).
+template <typename ACC, bool DOG>
+__global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              const float* __restrict__ prev, float* __restrict__ dog,
+                                                              int W, int H, const float* __restrict__ taps, int K) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = K >> 1;
+    const int x = blockIdx.x * 64 + lane;
+    if (x >= W) return;
+    const int yb = (blockIdx.y * 4 + wave) * P;
+    if (yb >= H) return;
+    auto rd = [&](int yy) -> float {
+        yy = max(0, min(yy, H - 1));
+        return in[(size_t)yy * W + x];
+    };
+    ACC acc[P];
+    float win[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        acc[p] = 0;
+        win[p] = rd(yb + p - r);
+    }
+    int k = 0;
+    for (; k + P <= K; k += P) {
+#pragma unroll
+        for (int u = 0; u < P; u++) {
+            const float g = taps[k + u];
+#pragma unroll
+            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+            win[u] = rd(yb + k + u + P - r);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < P; u++) {
+        if (k + u < K) {
+            const float g = taps[k + u];
+#pragma unroll
+            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+            win[u] = rd(yb + k + u + P - r);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int y = yb + p;
+        if (y < H) {
+            const float v = (float)acc[p];
+            const size_t idx = (size_t)y * W + x;
+            out[idx] = v;
+            if (DOG) dog[idx] = prev[idx] - v;
+        }
+    }
+}
+
+constexpr int kMaxColLds = 120 * 1024;  // largest LDS tile the column pass may request
+
+template <typename ACC>
+static void launch_blur_t(sift_hip_ctx* ctx, const float* src, float* tmp, float* dst, int W, int H,
+                          const float* d_taps, int K, const float* prev, float* dog) {
+    {
+        ProfScope ps(ctx, SIFT_HIP_K_BLUR_ROW);
+        const int n_in = 64 * P + K - 1 + P;
+        const size_t lds = (size_t)(n_in + (n_in >> 3) + 1) * sizeof(float);
+        dim3 grid((W + 64 * P - 1) / (64 * P), H);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC>), grid, dim3(64), lds, ctx->stream, src, tmp, W, H,
+                           d_taps, K);
+    }
+    {
+        ProfScope ps(ctx, SIFT_HIP_K_BLUR_COL);
+        // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
+        int TH = 128;
+        while (TH > 32 && (size_t)(TH + K - 1 + P) * 256 > 48 * 1024) TH >>= 1;
+        const size_t lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
+        if (lds <= (size_t)kMaxColLds) {
+            dim3 grid((W + 63) / 64, (H + TH - 1) / TH);
+            if (dog)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC, true>), grid, dim3(256), lds, ctx->stream, tmp,
+                                   dst, prev, dog, W, H, d_taps, K, TH);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC, false>), grid, dim3(256), lds, ctx->stream,
+                                   tmp, dst, prev, dog, W, H, d_taps, K, TH);
+        } else {
+            dim3 grid((W + 63) / 64, (H + 4 * P - 1) / (4 * P));
+            if (dog)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_global_kernel<ACC, true>), grid, dim3(256), 0, ctx->stream,
+                                   tmp, dst, prev, dog, W, H, d_taps, K);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_global_kernel<ACC, false>), grid, dim3(256), 0,
+                                   ctx->stream, tmp, dst, prev, dog, W, H, d_taps, K);
+        }
+    }
+}
+
+void launch_blur(sift_hip_ctx* ctx, const float* src, float* tmp, float* dst, int W, int H, const float* d_taps, int K,
+                 int blur_mode, const float* prev, float* dog) {
+    if (blur_mode == 1)
+        launch_blur_t<float>(ctx, src, tmp, dst, W, H, d_taps, K, prev, dog);
+    else
+        launch_blur_t<double>(ctx, src, tmp, dst, W, H, d_taps, K, prev, dog);
+}
+
+}  // namespace sifthip

@@ -1,0 +1,202 @@
+"""GPU parity: every stage of the HIP path against the CPU oracle, through the C ABI.
+
+Bars: bit-exact for the pyramid (blur_mode 0), keypoint records (position, layer,
+orientation bin, mm) and match indices/distances; descriptors within L2 1e-3 of
+the oracle's clamped histogram (device atan2f/expf and a different summation
+order), bytes within +-1.
+"""
+import numpy as np
+import pytest
+
+import sift_amd
+from sift_amd import SiftParams
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_library_is_hip_and_device_is_gfx950(sift):
+    assert sift.h
+
+
+@pytest.mark.parametrize("shape,p", [((61, 97), 1.6), ((48, 64), 3.2), ((150, 200), 4.525), ((17, 33), 9.05),
+                                     ((70, 1100), 2.2627418), ((300, 40), 25.6), ((5, 3), 1.6)])
+def test_gau_blur_bit_exact(sift, oracle, shape, p):
+    rng = np.random.default_rng(7)
+    img = rng.random(shape, dtype=np.float32)
+    got = sift.gau_blur(img, p)
+    want = oracle.gau_blur(img, p)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_gau_blur_long_kernel_uses_global_column_pass(sift, oracle):
+    # sigma 72.4 -> 435 taps: wider than the LDS-tiled column pass handles
+    rng = np.random.default_rng(8)
+    img = rng.random((96, 80), dtype=np.float32)
+    assert np.array_equal(bits(sift.gau_blur(img, 72.4)), bits(oracle.gau_blur(img, 72.4)))
+
+
+def test_gau_blur_fast_mode_close(sift, oracle):
+    rng = np.random.default_rng(9)
+    img = rng.random((120, 160), dtype=np.float32)
+    got = sift.gau_blur(img, 3.2, blur_mode=1)
+    want = oracle.gau_blur(img, 3.2)
+    assert np.max(np.abs(got - want)) < 2e-6
+
+
+def test_gau_blur_same_buffer_is_an_error(sift):
+    import ctypes as C
+
+    a = np.zeros((8, 8), np.float32)
+    rc = sift.lib.sift_hip_gau_blur(sift.h, C.c_void_p(a.ctypes.data), C.c_void_p(a.ctypes.data), 8, 8, 1.6, 0)
+    assert rc == sift_amd.capi.ERR_SAME
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (61, 97), (257, 333)])
+@pytest.mark.parametrize("ratio", [2.0, 1.0, 0.5, 0.25, 0.125])
+def test_first_bit_exact(sift, oracle, shape, ratio):
+    rng = np.random.default_rng(3)
+    img = rng.random(shape, dtype=np.float32)
+    assert np.array_equal(bits(sift.first(img, ratio)), bits(oracle.first(img, ratio)))
+
+
+def test_convert_gray_bit_exact(sift, oracle):
+    rng = np.random.default_rng(4)
+    rgb = rng.random((37, 53, 3), dtype=np.float32)
+    assert np.array_equal(bits(sift.convert_gray(rgb)), bits(oracle.convert_gray(rgb)))
+
+
+@pytest.mark.parametrize("octave", [0, 1, 2])
+def test_octave_levels_bit_exact(sift, oracle, octave):
+    img = sift_amd.blob_image(256, 192, seed=1)
+    g, d = sift.octave_levels(img, octave)
+    go, do = oracle.octave_levels(img, octave)
+    assert np.array_equal(bits(g), bits(go))
+    assert np.array_equal(bits(d), bits(do))
+
+
+def check_features(f, h, fo, ho):
+    assert len(f) == len(fo)
+    for k in ("size", "kai", "sigmaOCT", "x", "y", "sita"):
+        assert np.array_equal(f[k], fo[k]), k
+    assert np.array_equal(bits(f["mm"]), bits(fo["mm"]))
+    # descriptors: L2 of the clamped histogram within 1e-3, bytes within +-1
+    l2 = np.sqrt(((h.astype(np.float64) - ho) ** 2).sum(axis=1))
+    assert l2.max() < 1e-3, l2.max()
+    diff = np.abs(f["descr"].astype(np.int16) - fo["descr"].astype(np.int16))
+    assert diff.max() <= 1
+    assert (diff != 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("w,h,seed", [(256, 192, 1), (320, 200, 5), (640, 480, 1)])
+def test_extract_matches_oracle(sift, oracle, w, h, seed):
+    img = sift_amd.blob_image(w, h, seed=seed)
+    f, hist = sift.extract(img, want_hist=True)
+    fo, ho = oracle.extract(img)
+    assert len(fo) > 50
+    check_features(f, hist, fo, ho)
+
+
+def test_extract_fixed_octaves_is_prefix_of_auto(sift, oracle):
+    img = sift_amd.blob_image(320, 240, seed=2)
+    f2, _ = sift.extract(img, SiftParams(octaves=2))
+    fo, _ = oracle.extract(img, octaves=2)
+    assert len(f2) == len(fo)
+    assert np.array_equal(f2["x"], fo["x"]) and np.array_equal(f2["sita"], fo["sita"])
+
+
+def test_extract_rgb_goes_through_convert_gray(sift, oracle):
+    rng = np.random.default_rng(11)
+    g = sift_amd.blob_image(256, 192, seed=3)
+    rgb = np.stack([g, np.roll(g, 3, 1), np.roll(g, 5, 0)], axis=-1)
+    rgb = (rgb * rng.uniform(0.9, 1.0)).astype(np.float32)
+    f, h = sift.extract(rgb, want_hist=True)
+    fo, ho = oracle.extract(oracle.convert_gray(rgb))
+    check_features(f, h, fo, ho)
+
+
+def test_extract_nospc_reports_needed_capacity(sift):
+    import ctypes as C
+
+    img = sift_amd.blob_image(256, 192, seed=1)
+    out = np.zeros(10, sift_amd.FEAT_DTYPE)
+    n = C.c_int(0)
+    prm = SiftParams()._c()
+    rc = sift.lib.sift_hip_extract(sift.h, C.c_void_p(img.ctypes.data), 256, 192, 1, C.byref(prm),
+                                   C.c_void_p(out.ctypes.data), 10, C.byref(n), None)
+    assert rc == sift_amd.capi.ERR_NOSPC and n.value > 10
+    full, _ = sift.extract(img)
+    assert n.value == len(full)
+    assert np.array_equal(out["x"], full["x"][:10])
+
+
+def test_extract_flat_image_has_no_features(sift):
+    f, _ = sift.extract(np.full((96, 128), 0.5, np.float32))
+    assert len(f) == 0
+
+
+def test_extract_batch_equals_single_frames(sift):
+    frames = np.stack([sift_amd.blob_image(256, 192, seed=s) for s in (1, 2, 3)])
+    out, n = sift.extract_batch(frames, cap=4096)
+    for i in range(3):
+        f, _ = sift.extract(frames[i])
+        assert n[i] == len(f)
+        assert np.array_equal(out[i, : n[i]]["descr"], f["descr"])
+        assert np.array_equal(out[i, : n[i]]["x"], f["x"])
+
+
+@pytest.mark.parametrize("nq,nr", [(1, 1), (5, 2), (64, 64), (257, 129), (1000, 3000), (300, 1)])
+@pytest.mark.parametrize("form", [0, 1])
+def test_match_bit_exact(sift, oracle, nq, nr, form):
+    q, r = sift_amd.planted_descriptors(nq, nr, vmax=255, plant=0.2)
+    best, d1, d2 = sift.match_u8(q, r, 0.5, form)
+    bo, d1o, d2o = oracle.match_u8(q, r, 0.5, form)
+    assert np.array_equal(d1, d1o)
+    assert np.array_equal(d2, d2o)
+    assert np.array_equal(best, bo)
+
+
+def test_match_ties_pick_lowest_index(sift, oracle):
+    q, r = sift_amd.planted_descriptors(40, 600, vmax=102)
+    r[300] = r[7]
+    r[555] = r[7]
+    q[0] = r[7]
+    r[513] = r[299]
+    q[1] = r[299]
+    q[1, 5] ^= 1  # distance 1 to both copies: accepted at ratio 2, index must be the lower one
+    best, d1, d2 = sift.match_u8(q, r, 0.9, 0)
+    bo, d1o, d2o = oracle.match_u8(q, r, 0.9, 0)
+    assert d1[0] == 0 and d2[0] == 0
+    assert np.array_equal(best, bo) and np.array_equal(d1, d1o) and np.array_equal(d2, d2o)
+    bf, d1f, d2f = sift.match_u8(q, r, 2.0, 0)  # accept everything: index of the first minimum
+    bof, _, _ = oracle.match_u8(q, r, 2.0, 0)
+    assert bf[1] == 299 and np.array_equal(bf, bof)
+
+
+def test_match_on_extracted_descriptors_equals_forcematch(sift, oracle):
+    a = sift_amd.blob_image(320, 240, seed=1)
+    b = sift_amd.blob_image(320, 240, seed=1, shift_x=-12)
+    fa, _ = sift.extract(a)
+    fb, _ = sift.extract(b)
+    best, d1, d2 = sift.match_u8(fb["descr"], fa["descr"], 0.5, 1)
+    bo, d1o, d2o = oracle.force_match(fb["descr"].astype(np.float32), fa["descr"].astype(np.float32), 0.5)
+    assert np.array_equal(best, bo)
+    assert (best >= 0).sum() > 20
+    # matched keypoints are the same scene points, 12 px apart at full resolution
+    m = best >= 0
+    dx = fb["x"][m] / fb["size"][m] - fa["x"][best[m]] / fa["size"][best[m]]
+    assert np.median(np.abs(dx + 12)) <= 1.0
+
+
+def test_profile_counts_launches(sift):
+    img = sift_amd.blob_image(256, 192, seed=1)
+    sift.profile(True)
+    sift.profile_read(reset=True)
+    sift.extract(img, SiftParams(octaves=1))
+    prof = sift.profile_read(reset=True)
+    sift.profile(False)
+    assert prof["blur_row"][1] == 6 and prof["blur_col"][1] == 6 and prof["resample"][1] == 1
+    assert prof["blur_row"][0] > 0
