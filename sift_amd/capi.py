@@ -70,7 +70,8 @@ class SiftHipError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libsift_hip.so")
+    """In-tree build product; SIFT_HIP_LIB points at another build (kernel experiments)."""
+    return os.environ.get("SIFT_HIP_LIB") or os.path.join(_HERE, "lib", "libsift_hip.so")
 
 
 _lib = None

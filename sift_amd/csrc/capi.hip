@@ -241,8 +241,15 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         launch_detect(ctx, (const float*)ctx->dog_all.p, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap);
         launch_orient(ctx, (const float*)ctx->dog_all.p, PX, oc.W, d_lc, (const float*)ctx->table.p);
         launch_emit(ctx, oc.curr_size, d_lc, feat_cap);
+        int max_window = 1;
+        for (int li = 0; li < prm.intvls; li++) {
+            // descriptor radius of Sift.cpp:357 for this layer's integer-truncated sigma
+            const float hw = 3.f * (float)(int)oc.curr_sigma[li];
+            const int R = (int)(hw * std::sqrt(2.f) * (4 + 1.f) * 0.5f + 0.5f);
+            max_window = std::max(max_window, (2 * R + 1) * (2 * R + 1));
+        }
         launch_descr(ctx, (const float*)ctx->gau_all.p, PX, oc.W, oc.H, (const float*)ctx->table.p, feat_cap,
-                     want_hist ? (float*)ctx->hist.p : nullptr);
+                     want_hist ? (float*)ctx->hist.p : nullptr, max_window);
     }
     return check_async(ctx, "extract launch");
 }

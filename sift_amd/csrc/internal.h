@@ -113,8 +113,9 @@ void launch_orient(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, const 
                    const float* d_table);
 void launch_emit(sift_hip_ctx* ctx, float curr_size, const LayerConsts* d_lc, int feat_cap);
 // descriptor.hip
+// max_window: sample count (2R+1)^2 of the octave's largest descriptor window
 void launch_descr(sift_hip_ctx* ctx, const float* gau, size_t PX, int W, int H, const float* d_cs, int feat_cap,
-                  float* d_hist);
+                  float* d_hist, int max_window);
 // match.hip
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
               int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
