@@ -58,7 +58,7 @@ int ensure_pinned(sift_hip_ctx* ctx, DevBuf& b, size_t bytes) {
     return SIFT_HIP_OK;
 }
 
-void prof_begin(sift_hip_ctx* ctx, int cls) {
+void prof_begin(sift_hip_ctx* ctx, int cls, hipStream_t st) {
     sift_hip_ctx::Ev ev;
     ev.cls = cls;
     for (hipEvent_t* e : {&ev.a, &ev.b}) {
@@ -69,11 +69,11 @@ void prof_begin(sift_hip_ctx* ctx, int cls) {
             hipEventCreate(e);
         }
     }
-    hipEventRecord(ev.a, ctx->stream);
+    hipEventRecord(ev.a, st);
     ctx->events.push_back(ev);
 }
 
-void prof_end(sift_hip_ctx* ctx) { hipEventRecord(ctx->events.back().b, ctx->stream); }
+void prof_end(sift_hip_ctx* ctx, hipStream_t st) { hipEventRecord(ctx->events.back().b, st); }
 
 // ---- host constants ------------------------------------------------------------
 // Gaus::gau_meth / Gaus::gau_matrix, imglib/imglib.cpp:120-155, same operand types.
@@ -183,27 +183,46 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
     return SIFT_HIP_OK;
 }
 
-// Gaussian + DoG levels of octave `oi` from the gray image on the device.
-static int run_octave_pyramid(sift_hip_ctx* ctx, const float* d_gray, int oi) {
+// Stream + workspace of octave `oi`.  Lane 0 is the context's main stream; with
+// profiling on every lane uses it, so that kernel durations are not inflated by
+// other octaves' kernels sharing the GPU.
+static int get_lane(sift_hip_ctx* ctx, int oi, OctWs** out) {
+    while ((int)ctx->lanes.size() <= oi) {
+        OctWs ws;
+        if (ctx->lanes.empty()) {
+            ws.stream = ctx->stream;
+        } else {
+            if (hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking) != hipSuccess) return SIFT_HIP_ERR_HIP;
+            ws.own_stream = true;
+        }
+        if (hipEventCreateWithFlags(&ws.ev_emit, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming) != hipSuccess)
+            return SIFT_HIP_ERR_HIP;
+        ctx->lanes.push_back(ws);
+    }
+    *out = &ctx->lanes[oi];
+    return SIFT_HIP_OK;
+}
+
+// Gaussian levels of octave `oi` from the gray image on the device, on stream st.
+static int run_octave_pyramid(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, const float* d_gray, int oi) {
     const Plan& pl = ctx->plan;
     const OctavePlan& oc = pl.oct[oi];
     const size_t PX = (size_t)oc.W * oc.H;
     const int pyWidth = pl.prm.intvls + 3;
     int rc;
-    if ((rc = ensure(ctx, ctx->base, PX * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->tmp, PX * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->gau_all, PX * 4 * pyWidth))) return rc;
-    if ((rc = ensure(ctx, ctx->dog_all, PX * 4 * (pyWidth - 1)))) return rc;
-    float* base = (float*)ctx->base.p;
-    float* tmp = (float*)ctx->tmp.p;
-    float* gau = (float*)ctx->gau_all.p;
-    float* dog = (float*)ctx->dog_all.p;
+    if ((rc = ensure(ctx, ws.base, PX * 4))) return rc;
+    if ((rc = ensure(ctx, ws.tmp, PX * 4))) return rc;
+    if ((rc = ensure(ctx, ws.gau_all, PX * 4 * pyWidth))) return rc;
+    float* base = (float*)ws.base.p;
+    float* tmp = (float*)ws.tmp.p;
+    float* gau = (float*)ws.gau_all.p;
     const float* taps = (const float*)ctx->table.p;
-    launch_first(ctx, d_gray, pl.w, pl.h, oc.curr_size, base, oc.W, oc.H);
+    launch_first(ctx, st, d_gray, pl.w, pl.h, oc.curr_size, base, oc.W, oc.H);
     for (int i = 0; i < pyWidth; i++) {
         const float* src = (i == 0) ? base : gau + (size_t)(i - 1) * PX;
-        launch_blur(ctx, src, tmp, gau + (size_t)i * PX, oc.W, oc.H, taps + oc.tap_off[i], oc.tap_len[i],
-                    pl.prm.blur_mode, i ? src : nullptr, i ? dog + (size_t)(i - 1) * PX : nullptr);
+        launch_blur(ctx, st, src, tmp, gau + (size_t)i * PX, oc.W, oc.H, taps + oc.tap_off[i], oc.tap_len[i],
+                    pl.prm.blur_mode);
     }
     return SIFT_HIP_OK;
 }
@@ -213,56 +232,87 @@ static int check_async(sift_hip_ctx* ctx, const char* what) {
 }
 
 // The whole of Sift::pyramid for one device-resident gray frame; results stay on
-// the device (ctx->feat / ctx->hist / counters).  No host synchronisation.
+// the device (ctx->feat / ctx->hist / counters).  No host synchronisation.  The
+// caller's prior work on ctx->stream (the frame upload) is ordered before every
+// octave; when this returns, ctx->stream is ordered after every octave.
 static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params& prm,
                            int feat_cap, int cand_cap, bool want_hist) {
     int rc = build_plan(ctx, w, h, prm);
     if (rc) return rc;
     const Plan& pl = ctx->plan;
-    if ((rc = ensure(ctx, ctx->counters, CNT_SLOTS * sizeof(int)))) return rc;
+    const int noct = (int)pl.oct.size();
+    if ((rc = ensure(ctx, ctx->gcounters, G_SLOTS * sizeof(int)))) return rc;
     if ((rc = ensure(ctx, ctx->feat, (size_t)std::max(1, feat_cap) * sizeof(sift_hip_feat)))) return rc;
     if (want_hist && (rc = ensure(ctx, ctx->hist, (size_t)std::max(1, feat_cap) * 128 * sizeof(float)))) return rc;
-    if ((rc = ensure(ctx, ctx->cand, (size_t)cand_cap * sizeof(Cand)))) return rc;
-    if ((rc = ensure(ctx, ctx->cand_mask, (size_t)cand_cap * sizeof(unsigned long long)))) return rc;
-    if ((rc = ensure(ctx, ctx->cand_mm, (size_t)cand_cap * 36 * sizeof(float)))) return rc;
-    if (!hip_ok(ctx, hipMemsetAsync(ctx->counters.p, 0, CNT_SLOTS * sizeof(int), ctx->stream), "reset counters"))
-        return SIFT_HIP_ERR_HIP;
-    const float thr = (float)((double)prm.dx_thr / 2.0);
-    for (int oi = 0; oi < (int)pl.oct.size(); oi++) {
+    // all allocation first: ensure() may synchronise, which must not happen between launches
+    for (int oi = 0; oi < noct; oi++) {
+        OctWs* ws;
+        if ((rc = get_lane(ctx, oi, &ws))) return rc;
         const OctavePlan& oc = pl.oct[oi];
         const size_t PX = (size_t)oc.W * oc.H;
         const int WW = (oc.W + 63) / 64;
         const int nrows = prm.intvls * oc.H;
-        if ((rc = ensure(ctx, ctx->masks, (size_t)nrows * WW * 8))) return rc;
-        if ((rc = ensure(ctx, ctx->row_cnt, (size_t)nrows * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->row_off, (size_t)nrows * 4))) return rc;
-        if ((rc = run_octave_pyramid(ctx, d_gray, oi))) return rc;
-        const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
-        launch_detect(ctx, (const float*)ctx->dog_all.p, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap);
-        launch_orient(ctx, (const float*)ctx->dog_all.p, PX, oc.W, d_lc, (const float*)ctx->table.p);
-        launch_emit(ctx, oc.curr_size, d_lc, feat_cap);
-        int max_window = 1;
-        for (int li = 0; li < prm.intvls; li++) {
-            // descriptor radius of Sift.cpp:357 for this layer's integer-truncated sigma
-            const float hw = 3.f * (float)(int)oc.curr_sigma[li];
-            const int R = (int)(hw * std::sqrt(2.f) * (4 + 1.f) * 0.5f + 0.5f);
-            max_window = std::max(max_window, (2 * R + 1) * (2 * R + 1));
-        }
-        launch_descr(ctx, (const float*)ctx->gau_all.p, PX, oc.W, oc.H, (const float*)ctx->table.p, feat_cap,
-                     want_hist ? (float*)ctx->hist.p : nullptr, max_window);
+        if ((rc = ensure(ctx, ws->base, PX * 4))) return rc;
+        if ((rc = ensure(ctx, ws->tmp, PX * 4))) return rc;
+        if ((rc = ensure(ctx, ws->gau_all, PX * 4 * (prm.intvls + 3)))) return rc;
+        if ((rc = ensure(ctx, ws->masks, (size_t)nrows * WW * 8))) return rc;
+        if ((rc = ensure(ctx, ws->row_cnt, (size_t)nrows * 4))) return rc;
+        if ((rc = ensure(ctx, ws->row_off, (size_t)nrows * 4))) return rc;
+        if ((rc = ensure(ctx, ws->cand, (size_t)cand_cap * sizeof(Cand)))) return rc;
+        if ((rc = ensure(ctx, ws->cand_mask, (size_t)cand_cap * sizeof(unsigned long long)))) return rc;
+        if ((rc = ensure(ctx, ws->cand_mm, (size_t)cand_cap * 36 * sizeof(float)))) return rc;
+        if ((rc = ensure(ctx, ws->counters, CNT_SLOTS * sizeof(int)))) return rc;
     }
+    if (!hip_ok(ctx, hipMemsetAsync(ctx->gcounters.p, 0, G_SLOTS * sizeof(int), ctx->stream), "reset counters"))
+        return SIFT_HIP_ERR_HIP;
+    hipEventRecord(ctx->ev_start, ctx->stream);
+    const float thr = (float)((double)prm.dx_thr / 2.0);
+    const bool serial = ctx->profiling;
+    for (int oi = 0; oi < noct; oi++) {
+        OctWs& ws = ctx->lanes[oi];
+        const hipStream_t lane_stream = ws.stream;
+        if (serial) ws.stream = ctx->stream;
+        const hipStream_t st = ws.stream;
+        if (st != ctx->stream) hipStreamWaitEvent(st, ctx->ev_start, 0);
+        const OctavePlan& oc = pl.oct[oi];
+        const size_t PX = (size_t)oc.W * oc.H;
+        rc = run_octave_pyramid(ctx, ws, st, d_gray, oi);
+        if (!rc) {
+            const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
+            launch_detect(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap);
+            launch_orient(ctx, ws, PX, oc.W, d_lc, (const float*)ctx->table.p);
+            // features are appended in octave order: wait for the previous octave's emit
+            if (oi > 0 && ctx->lanes[oi - 1].stream != st) hipStreamWaitEvent(st, ctx->lanes[oi - 1].ev_emit, 0);
+            launch_emit(ctx, ws, oc.curr_size, d_lc, feat_cap);
+            hipEventRecord(ws.ev_emit, st);
+            int max_window = 1;
+            for (int li = 0; li < prm.intvls; li++) {
+                // descriptor radius of Sift.cpp:357 for this layer's integer-truncated sigma
+                const float hw = 3.f * (float)(int)oc.curr_sigma[li];
+                const int R = (int)(hw * std::sqrt(2.f) * (4 + 1.f) * 0.5f + 0.5f);
+                max_window = std::max(max_window, (2 * R + 1) * (2 * R + 1));
+            }
+            launch_descr(ctx, ws, PX, oc.W, oc.H, (const float*)ctx->table.p, feat_cap,
+                         want_hist ? (float*)ctx->hist.p : nullptr, max_window);
+            hipEventRecord(ws.ev_done, st);
+        }
+        ws.stream = lane_stream;
+        if (rc) return rc;
+    }
+    if (!serial)
+        for (int oi = 1; oi < noct; oi++) hipStreamWaitEvent(ctx->stream, ctx->lanes[oi].ev_done, 0);
     return check_async(ctx, "extract launch");
 }
 
 // Copies the counters back, then the features (and histograms) that fit.
 static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow) {
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, CNT_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
                                     ctx->stream), "read counters"))
         return SIFT_HIP_ERR_HIP;
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "extract")) return SIFT_HIP_ERR_HIP;
-    *cand_overflow = ctx->h_counters[CNT_CAND_OVERFLOW];
+    *cand_overflow = ctx->h_counters[G_CAND_OVERFLOW];
     if (*cand_overflow) return SIFT_HIP_OK;
-    const int total = ctx->h_counters[CNT_FEAT_TOTAL];
+    const int total = ctx->h_counters[G_FEAT_TOTAL];
     *n = total;
     const int m = std::min(total, cap);
     if (m > 0) {
@@ -321,7 +371,8 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->h_counters, CNT_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counters, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         sift_hip_destroy(ctx);
         return SIFT_HIP_ERR_HIP;
     }
@@ -334,12 +385,22 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
-    DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->base, &ctx->tmp, &ctx->masks, &ctx->row_cnt, &ctx->row_off,
-                      &ctx->cand, &ctx->cand_mask, &ctx->cand_mm, &ctx->feat, &ctx->hist, &ctx->table,
-                      &ctx->layer_consts, &ctx->counters, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best,
-                      &ctx->d1, &ctx->d2, &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->gau_all, &ctx->dog_all};
+    for (OctWs& ws : ctx->lanes) {
+        if (ws.own_stream && ws.stream) hipStreamSynchronize(ws.stream);
+        DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
+                        &ws.cand_mm, &ws.counters};
+        for (DevBuf* b : wb)
+            if (b->p) hipFree(b->p);
+        if (ws.ev_emit) hipEventDestroy(ws.ev_emit);
+        if (ws.ev_done) hipEventDestroy(ws.ev_done);
+        if (ws.own_stream && ws.stream) hipStreamDestroy(ws.stream);
+    }
+    DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->feat, &ctx->hist, &ctx->table, &ctx->layer_consts,
+                      &ctx->gcounters, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
+                      &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
+    if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
     if (ctx->h_feat.p) hipHostFree(ctx->h_feat.p);
     if (ctx->h_hist.p) hipHostFree(ctx->h_hist.p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
@@ -417,7 +478,7 @@ int sift_hip_extract(sift_hip_ctx* ctx, const float* img, int w, int h, int chan
         if ((rc = ensure(ctx, ctx->in_rgb, px * 12))) return rc;
         if (!hip_ok(ctx, hipMemcpyAsync(ctx->in_rgb.p, img, px * 12, hipMemcpyHostToDevice, ctx->stream), "upload"))
             return SIFT_HIP_ERR_HIP;
-        launch_gray(ctx, (const float*)ctx->in_rgb.p, (float*)ctx->in_img.p, px);
+        launch_gray(ctx, ctx->stream, (const float*)ctx->in_rgb.p, (float*)ctx->in_img.p, px);
     } else {
         if (!hip_ok(ctx, hipMemcpyAsync(ctx->in_img.p, img, px * 4, hipMemcpyHostToDevice, ctx->stream), "upload"))
             return SIFT_HIP_ERR_HIP;
@@ -489,8 +550,8 @@ int sift_hip_gau_blur(sift_hip_ctx* ctx, const float* in, float* out, int w, int
     if ((rc = ensure(ctx, ctx->best, g.size() * 4 + 64))) return rc;  // scratch for this call's taps
     hipMemcpyAsync(ctx->best.p, g.data(), g.size() * 4, hipMemcpyHostToDevice, ctx->stream);
     hipMemcpyAsync(ctx->io_a.p, in, px * 4, hipMemcpyHostToDevice, ctx->stream);
-    launch_blur(ctx, (const float*)ctx->io_a.p, (float*)ctx->tmp.p, (float*)ctx->io_b.p, w, h,
-                (const float*)ctx->best.p, (int)g.size(), blur_mode, nullptr, nullptr);
+    launch_blur(ctx, ctx->stream, (const float*)ctx->io_a.p, (float*)ctx->tmp.p, (float*)ctx->io_b.p, w, h,
+                (const float*)ctx->best.p, (int)g.size(), blur_mode);
     hipMemcpyAsync(out, ctx->io_b.p, px * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "gau_blur")) return SIFT_HIP_ERR_HIP;
     return check_async(ctx, "gau_blur");
@@ -505,7 +566,7 @@ int sift_hip_first(sift_hip_ctx* ctx, const float* in, int w, int h, float ratio
     if ((rc = ensure(ctx, ctx->io_a, (size_t)w * h * 4))) return rc;
     if ((rc = ensure(ctx, ctx->io_b, (size_t)nw * nh * 4))) return rc;
     hipMemcpyAsync(ctx->io_a.p, in, (size_t)w * h * 4, hipMemcpyHostToDevice, ctx->stream);
-    launch_first(ctx, (const float*)ctx->io_a.p, w, h, ratio, (float*)ctx->io_b.p, nw, nh);
+    launch_first(ctx, ctx->stream, (const float*)ctx->io_a.p, w, h, ratio, (float*)ctx->io_b.p, nw, nh);
     hipMemcpyAsync(out, ctx->io_b.p, (size_t)nw * nh * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "first")) return SIFT_HIP_ERR_HIP;
     return check_async(ctx, "first");
@@ -517,7 +578,7 @@ int sift_hip_convert_gray(sift_hip_ctx* ctx, const float* rgb, int n, float* gra
     if ((rc = ensure(ctx, ctx->io_a, (size_t)n * 12))) return rc;
     if ((rc = ensure(ctx, ctx->io_b, (size_t)n * 4))) return rc;
     hipMemcpyAsync(ctx->io_a.p, rgb, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream);
-    launch_gray(ctx, (const float*)ctx->io_a.p, (float*)ctx->io_b.p, (size_t)n);
+    launch_gray(ctx, ctx->stream, (const float*)ctx->io_a.p, (float*)ctx->io_b.p, (size_t)n);
     hipMemcpyAsync(gray, ctx->io_b.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "convert_gray")) return SIFT_HIP_ERR_HIP;
     return check_async(ctx, "convert_gray");
@@ -537,10 +598,16 @@ int sift_hip_octave_levels(sift_hip_ctx* ctx, const float* gray, int w, int h, c
     const size_t PX = (size_t)oc.W * oc.H;
     if ((rc = ensure(ctx, ctx->in_img, (size_t)w * h * 4))) return rc;
     hipMemcpyAsync(ctx->in_img.p, gray, (size_t)w * h * 4, hipMemcpyHostToDevice, ctx->stream);
-    if ((rc = run_octave_pyramid(ctx, (const float*)ctx->in_img.p, octave))) return rc;
+    OctWs* ws;
+    if ((rc = get_lane(ctx, 0, &ws))) return rc;
+    if ((rc = run_octave_pyramid(ctx, *ws, ctx->stream, (const float*)ctx->in_img.p, octave))) return rc;
     const int pyWidth = prm.intvls + 3;
-    if (gau) hipMemcpyAsync(gau, ctx->gau_all.p, PX * 4 * pyWidth, hipMemcpyDeviceToHost, ctx->stream);
-    if (dog) hipMemcpyAsync(dog, ctx->dog_all.p, PX * 4 * (pyWidth - 1), hipMemcpyDeviceToHost, ctx->stream);
+    if (gau) hipMemcpyAsync(gau, ws->gau_all.p, PX * 4 * pyWidth, hipMemcpyDeviceToHost, ctx->stream);
+    if (dog) {
+        if ((rc = ensure(ctx, ctx->dog_all, PX * 4 * (pyWidth - 1)))) return rc;
+        launch_dog(ctx, ctx->stream, (const float*)ws->gau_all.p, (float*)ctx->dog_all.p, PX, pyWidth);
+        hipMemcpyAsync(dog, ctx->dog_all.p, PX * 4 * (pyWidth - 1), hipMemcpyDeviceToHost, ctx->stream);
+    }
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "octave_levels")) return SIFT_HIP_ERR_HIP;
     *ow = oc.W;
     *oh = oc.H;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
     const int tid = threadIdx.x, nthr = blockDim.x;
     unsigned long long* myhist = hist + (tid & (NCOPY - 1)) * HSTRIDE;
     const int begin = counters[CNT_OCT_BEGIN];
-    const int end = min(counters[CNT_FEAT_TOTAL], feat_cap);
+    const int end = min(counters[CNT_OCT_END], feat_cap);
     const float PI2 = (float)(2.f * 3.14159265358979323846);
     const float bins_per_rad = 8 / PI2;
     const float exp_denom = 4 * 4 * 0.5f;
@@ -147,15 +147,15 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
     }
 }
 
-void launch_descr(sift_hip_ctx* ctx, const float* gau, size_t PX, int W, int H, const float* d_cs, int feat_cap,
+void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const float* d_cs, int feat_cap,
                   float* d_hist, int max_window) {
-    ProfScope ps(ctx, SIFT_HIP_K_DESCR);
+    ProfScope ps(ctx, SIFT_HIP_K_DESCR, ws.stream);
     // threads per feature: about 48 window samples per thread for the octave's largest window
     int nthr = ((max_window / 48) + 63) / 64 * 64;
     nthr = std::max(64, std::min(1024, nthr));
     const int blocks = 256 * std::max(2, 2048 / nthr);
-    hipLaunchKernelGGL(descr_kernel, dim3(blocks), dim3(nthr), 0, ctx->stream, gau, PX, W, H, d_cs,
-                       (sift_hip_feat*)ctx->feat.p, feat_cap, (const int*)ctx->counters.p, d_hist);
+    hipLaunchKernelGGL(descr_kernel, dim3(blocks), dim3(nthr), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H,
+                       d_cs, (sift_hip_feat*)ctx->feat.p, feat_cap, (const int*)ws.counters.p, d_hist);
 }
 
 }  // namespace sifthip

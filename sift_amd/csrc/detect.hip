@@ -1,6 +1,6 @@
 // Keypoint detection for one octave on gfx950:
 //   detect_rows   3x3x3 extremum + contrast + edge test, one workgroup per image
-//                 row of one DoG layer; wavefront ballots become 64-pixel mask words
+//                 row (all DoG layers); wavefront ballots become 64-pixel mask words
 //   scan_rows     exclusive prefix sum of the per-row counts (one workgroup)
 //   expand_rows   mask words -> ordered candidate list (wave prefix sums)
 //   orient        36-bin orientation histogram, one wavefront per candidate
@@ -13,21 +13,28 @@
 
 namespace sifthip {
 
+// The DoG layers are never stored: dog[k] = gau[k] - gau[k+1] (Sift.cpp:161-168) is
+// one float subtraction, recomputed wherever a DoG value is needed.  The detector
+// streams Gaussian levels 1..intvls+1 once; only pixels that pass the contrast
+// test (a few percent) touch their 3x3x3 neighbourhood.
+__device__ __forceinline__ float dogv(const float* __restrict__ gau, size_t PX, int k, size_t q) {
+    return gau[(size_t)k * PX + q] - gau[(size_t)(k + 1) * PX + q];
+}
+
 // ---- findMaxMin (Sift.cpp:86-104) + harris_corner (Sift.cpp:105-129) -------------
-__device__ __forceinline__ bool is_keypoint(const float* __restrict__ dprev, const float* __restrict__ dcur,
-                                            const float* __restrict__ dnext, int W, int y, int x, float thr,
-                                            float rad) {
+// li = DoG layer index (1..intvls), v = dog[li] at (y, x), already past |v| > thr.
+__device__ __forceinline__ bool is_keypoint(const float* __restrict__ gau, size_t PX, int li, int W, int y, int x,
+                                            float v, float rad) {
     const size_t c = (size_t)y * W + x;
-    const float v = dcur[c];
-    if (!(fabsf(v) > thr)) return false;
-    const float* lay[3] = {dprev, dcur, dnext};
+    float cur[9];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = -1; k <= 1; k++) {
 #pragma unroll
         for (int j = -1; j <= 1; j++) {
 #pragma unroll
             for (int i = -1; i <= 1; i++) {
-                const float nb = lay[k][c + (ptrdiff_t)j * W + i];
+                const float nb = dogv(gau, PX, li + k, c + (ptrdiff_t)j * W + i);
+                if (k == 0) cur[(j + 1) * 3 + (i + 1)] = nb;
                 if (v > 0.f && v < nb) return false;
                 if (v < 0.f && v > nb) return false;
             }
@@ -35,10 +42,9 @@ __device__ __forceinline__ bool is_keypoint(const float* __restrict__ dprev, con
     }
     // edge test; the "r" of the reference call is the histogram radius
     const float thre = ((rad + 1.f) * (rad + 1.f)) / rad;
-    const float l = dcur[c - 1], rr = dcur[c + 1], u = dcur[c - W], d = dcur[c + W];
-    const float Dxx = 2.f * v - l - rr;
-    const float Dyy = 2.f * v - u - d;
-    float Dxy = dcur[c + W + 1] + dcur[c - W - 1] - dcur[c - W + 1] - dcur[c + W - 1];
+    const float Dxx = 2.f * v - cur[3] - cur[5];
+    const float Dyy = 2.f * v - cur[1] - cur[7];
+    float Dxy = cur[8] + cur[0] - cur[2] - cur[6];
     Dxy /= 4.f;
     const float Tr = Dxx + Dyy;
     const float Det = Dxx * Dyy - Dxy * Dxy;
@@ -46,36 +52,49 @@ __device__ __forceinline__ bool is_keypoint(const float* __restrict__ dprev, con
     return val < thre;
 }
 
-// grid.x = intvls * H rows.  Writes every mask word of the row (zeros included)
-// and the row's candidate count.
-__global__ __launch_bounds__(256) void detect_rows_kernel(const float* __restrict__ dog, size_t PX, int W, int H,
-                                                          const LayerConsts* __restrict__ lc, float thr, int WW,
-                                                          unsigned long long* __restrict__ masks,
+// grid.x = H image rows; each workgroup handles its row for every DoG layer.
+// Writes every mask word (zeros included) and the per-(layer,row) counts.
+constexpr int kMaxIntvls = 8;
+__global__ __launch_bounds__(256) void detect_rows_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
+                                                          int intvls, const LayerConsts* __restrict__ lc, float thr,
+                                                          int WW, unsigned long long* __restrict__ masks,
                                                           int* __restrict__ row_cnt) {
-    __shared__ int s_cnt[4];
-    const int row = blockIdx.x;
-    const int li = row / H;  // layer index 0..intvls-1  (DoG layer li+1)
-    const int y = row - li * H;
-    const int rad = lc[li].radius;
-    const float* dprev = dog + (size_t)li * PX;
-    const float* dcur = dprev + PX;
-    const float* dnext = dcur + PX;
+    __shared__ int s_cnt[kMaxIntvls][4];
+    const int y = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // scan bounds of Sift.cpp:178-179: r+1 <= y < H-r-1, r+1 <= x < W-r-1
-    const bool row_ok = (H >= 2 * rad + 3) && (W >= 2 * rad + 3) && y >= rad + 1 && y < H - rad - 1;
-    int cnt = 0;
+    int cnt[kMaxIntvls];
+#pragma unroll
+    for (int l = 0; l < kMaxIntvls; l++) cnt[l] = 0;
     for (int xb = 0; xb < WW * 64; xb += 256) {
         const int x = xb + threadIdx.x;
-        bool hit = false;
-        if (row_ok && x >= rad + 1 && x < W - rad - 1) hit = is_keypoint(dprev, dcur, dnext, W, y, x, thr, (float)rad);
-        const unsigned long long m = __ballot(hit);
-        const int word = (xb >> 6) + wave;
-        if (lane == 0 && word < WW) masks[(size_t)row * WW + word] = m;
-        cnt += __popcll(m);
+        const size_t c = (size_t)y * W + min(x, W - 1);
+        float ga = gau[PX + c];  // level 1
+#pragma unroll
+        for (int l = 0; l < kMaxIntvls; l++) {
+            if (l < intvls) {
+                const float gb = gau[(size_t)(l + 2) * PX + c];
+                const float v = ga - gb;  // dog[l+1]
+                ga = gb;
+                const int rad = lc[l].radius;
+                // scan bounds of Sift.cpp:178-179: r+1 <= y < H-r-1, r+1 <= x < W-r-1
+                bool hit = (H >= 2 * rad + 3) && (W >= 2 * rad + 3) && y >= rad + 1 && y < H - rad - 1 &&
+                           x >= rad + 1 && x < W - rad - 1 && (fabsf(v) > thr);
+                if (hit) hit = is_keypoint(gau, PX, l + 1, W, y, x, v, (float)rad);
+                const unsigned long long m = __ballot(hit);
+                const int word = (xb >> 6) + wave;
+                if (lane == 0 && word < WW) masks[((size_t)l * H + y) * WW + word] = m;
+                cnt[l] += __popcll(m);
+            }
+        }
     }
-    if (lane == 0) s_cnt[wave] = cnt;
+#pragma unroll
+    for (int l = 0; l < kMaxIntvls; l++)
+        if (l < intvls && lane == 0) s_cnt[l][wave] = cnt[l];
     __syncthreads();
-    if (threadIdx.x == 0) row_cnt[row] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (threadIdx.x < intvls) {
+        const int l = threadIdx.x;
+        row_cnt[l * H + y] = s_cnt[l][0] + s_cnt[l][1] + s_cnt[l][2] + s_cnt[l][3];
+    }
 }
 
 // Exclusive scan of n ints by one 1024-thread workgroup; total -> counters.
@@ -108,7 +127,8 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* s_warp, int& tot
 }
 
 __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ row_cnt, int* __restrict__ row_off,
-                                                         int nrows, int cand_cap, int* __restrict__ counters) {
+                                                         int nrows, int cand_cap, int* __restrict__ counters,
+                                                         int* __restrict__ gcounters) {
     __shared__ int s_warp[40];
     int running = 0;
     for (int b = 0; b < nrows; b += 1024) {
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__
     if (threadIdx.x == 0) {
         counters[CNT_NCAND_TOTAL] = running;
         counters[CNT_NCAND] = min(running, cand_cap);
-        if (running > cand_cap) counters[CNT_CAND_OVERFLOW] = max(counters[CNT_CAND_OVERFLOW], running);
+        if (running > cand_cap) atomicMax(&gcounters[G_CAND_OVERFLOW], running);
     }
 }
 
@@ -190,7 +210,7 @@ __device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
 // chunks, then lane b walks the chunk in order and adds the entries of bin b.
 constexpr int ORI_CH = 2048;
 
-__global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ dog, size_t PX, int W,
+__global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ gau, size_t PX, int W,
                                                     const LayerConsts* __restrict__ lc,
                                                     const float* __restrict__ table, const Cand* __restrict__ cand,
                                                     const int* __restrict__ counters,
@@ -205,7 +225,8 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ do
         const int r = L.radius;
         const int n = 2 * r + 1;
         const int total = n * n;
-        const float* img = dog + (size_t)cd.layer * PX;
+        const float* g1 = gau + (size_t)cd.layer * PX;  // dog[layer] = gau[layer] - gau[layer+1]
+        const float* g2 = g1 + PX;
         const float* g = table + L.wts_off;
         float sum = 0.f;
         for (int e0 = 0; e0 < total; e0 += ORI_CH) {
@@ -215,8 +236,8 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ do
                 const int jj = idx / n;
                 const int ii = idx - jj * n;
                 const size_t p = (size_t)(cd.y - r + jj) * W + (cd.x - r + ii);
-                const float dx = img[p + 1] - img[p - 1];
-                const float dy = img[p + W] - img[p - W];
+                const float dx = (g1[p + 1] - g2[p + 1]) - (g1[p - 1] - g2[p - 1]);
+                const float dy = (g1[p + W] - g2[p + W]) - (g1[p - W] - g2[p - W]);
                 float mag = sqrtf(dx * dx + dy * dy);
                 const float th = fast_atan2f_deg(dy, dx);
                 mag = mag * g[ii];
@@ -247,10 +268,10 @@ __global__ __launch_bounds__(1024) void emit_kernel(const Cand* __restrict__ can
                                                     const unsigned long long* __restrict__ cmask,
                                                     const float* __restrict__ cmm, const LayerConsts* __restrict__ lc,
                                                     float curr_size, sift_hip_feat* __restrict__ feat, int feat_cap,
-                                                    int* __restrict__ counters) {
+                                                    int* __restrict__ counters, int* __restrict__ gcounters) {
     __shared__ int s_warp[40];
     const int ncand = counters[CNT_NCAND];
-    const int begin = counters[CNT_FEAT_TOTAL];
+    const int begin = gcounters[G_FEAT_TOTAL];
     int running = begin;
     for (int b = 0; b < ncand; b += 1024) {
         const int i = b + threadIdx.x;
@@ -283,42 +304,42 @@ __global__ __launch_bounds__(1024) void emit_kernel(const Cand* __restrict__ can
     __syncthreads();
     if (threadIdx.x == 0) {
         counters[CNT_OCT_BEGIN] = begin;
-        counters[CNT_FEAT_TOTAL] = running;
+        counters[CNT_OCT_END] = running;
+        gcounters[G_FEAT_TOTAL] = running;
     }
 }
 
-void launch_detect(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
+void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
                    float thr, int cand_cap) {
     const int WW = (W + 63) / 64;
     const int nrows = intvls * H;
     {
-        ProfScope ps(ctx, SIFT_HIP_K_DETECT);
-        hipLaunchKernelGGL(detect_rows_kernel, dim3(nrows), dim3(256), 0, ctx->stream, dog, PX, W, H, d_lc, thr, WW,
-                           (unsigned long long*)ctx->masks.p, (int*)ctx->row_cnt.p);
+        ProfScope ps(ctx, SIFT_HIP_K_DETECT, ws.stream);
+        hipLaunchKernelGGL(detect_rows_kernel, dim3(H), dim3(256), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H,
+                           intvls, d_lc, thr, WW, (unsigned long long*)ws.masks.p, (int*)ws.row_cnt.p);
     }
     {
-        ProfScope ps(ctx, SIFT_HIP_K_COMPACT);
-        hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int*)ctx->row_cnt.p,
-                           (int*)ctx->row_off.p, nrows, cand_cap, (int*)ctx->counters.p);
-        hipLaunchKernelGGL(expand_rows_kernel, dim3(nrows), dim3(64), 0, ctx->stream,
-                           (const unsigned long long*)ctx->masks.p, (const int*)ctx->row_cnt.p,
-                           (const int*)ctx->row_off.p, H, WW, (Cand*)ctx->cand.p, cand_cap);
+        ProfScope ps(ctx, SIFT_HIP_K_COMPACT, ws.stream);
+        hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, ws.stream, (const int*)ws.row_cnt.p,
+                           (int*)ws.row_off.p, nrows, cand_cap, (int*)ws.counters.p, (int*)ctx->gcounters.p);
+        hipLaunchKernelGGL(expand_rows_kernel, dim3(nrows), dim3(64), 0, ws.stream,
+                           (const unsigned long long*)ws.masks.p, (const int*)ws.row_cnt.p, (const int*)ws.row_off.p,
+                           H, WW, (Cand*)ws.cand.p, cand_cap);
     }
 }
 
-void launch_orient(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, const LayerConsts* d_lc,
-                   const float* d_table) {
-    ProfScope ps(ctx, SIFT_HIP_K_ORIENT);
-    hipLaunchKernelGGL(orient_kernel, dim3(256 * 12), dim3(64), 0, ctx->stream, dog, PX, W, d_lc, d_table,
-                       (const Cand*)ctx->cand.p, (const int*)ctx->counters.p, (unsigned long long*)ctx->cand_mask.p,
-                       (float*)ctx->cand_mm.p);
+void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table) {
+    ProfScope ps(ctx, SIFT_HIP_K_ORIENT, ws.stream);
+    hipLaunchKernelGGL(orient_kernel, dim3(256 * 12), dim3(64), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, d_lc,
+                       d_table, (const Cand*)ws.cand.p, (const int*)ws.counters.p, (unsigned long long*)ws.cand_mask.p,
+                       (float*)ws.cand_mm.p);
 }
 
-void launch_emit(sift_hip_ctx* ctx, float curr_size, const LayerConsts* d_lc, int feat_cap) {
-    ProfScope ps(ctx, SIFT_HIP_K_EMIT);
-    hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const Cand*)ctx->cand.p,
-                       (const unsigned long long*)ctx->cand_mask.p, (const float*)ctx->cand_mm.p, d_lc, curr_size,
-                       (sift_hip_feat*)ctx->feat.p, feat_cap, (int*)ctx->counters.p);
+void launch_emit(sift_hip_ctx* ctx, OctWs& ws, float curr_size, const LayerConsts* d_lc, int feat_cap) {
+    ProfScope ps(ctx, SIFT_HIP_K_EMIT, ws.stream);
+    hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(1024), 0, ws.stream, (const Cand*)ws.cand.p,
+                       (const unsigned long long*)ws.cand_mask.p, (const float*)ws.cand_mm.p, d_lc, curr_size,
+                       (sift_hip_feat*)ctx->feat.p, feat_cap, (int*)ws.counters.p, (int*)ctx->gcounters.p);
 }
 
 }  // namespace sifthip

@@ -15,19 +15,34 @@ struct Cand {  // an extremum that passed the contrast and edge tests
     int32_t x, y, layer;
 };
 
-// Slots of the per-context device counter block.
+// Slots of an octave's device counter block.
 enum Counter {
-    CNT_NCAND = 0,        // candidates stored for the current octave (<= capacity)
-    CNT_NCAND_TOTAL = 1,  // candidates found for the current octave
-    CNT_FEAT_TOTAL = 2,   // features found so far (all octaves, may exceed capacity)
-    CNT_OCT_BEGIN = 3,    // CNT_FEAT_TOTAL before the current octave
-    CNT_CAND_OVERFLOW = 4,
+    CNT_NCAND = 0,        // candidates stored for this octave (<= capacity)
+    CNT_NCAND_TOTAL = 1,  // candidates found for this octave
+    CNT_OCT_BEGIN = 2,    // index of this octave's first feature in the output array
+    CNT_OCT_END = 3,      // one past its last feature (may exceed the capacity)
     CNT_SLOTS = 8
+};
+// Slots of the per-context (all octaves) counter block.
+enum GlobalCounter {
+    G_FEAT_TOTAL = 0,     // features emitted so far, octave by octave
+    G_CAND_OVERFLOW = 1,  // largest candidate count that did not fit, 0 if all fit
+    G_SLOTS = 8
 };
 
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+};
+
+// Octaves are independent until their features are appended (Sift.cpp:145-149:
+// every octave restarts from the original image), so each one gets its own HIP
+// stream and workspace; only emit/describe are chained in octave order.
+struct OctWs {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_emit = nullptr, ev_done = nullptr;
+    DevBuf base, tmp, gau_all, masks, row_cnt, row_off, cand, cand_mask, cand_mm, counters;
 };
 
 struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-183)
@@ -60,9 +75,10 @@ struct sift_hip_ctx {
 
     sifthip::Plan plan;
     // device workspace (grown on demand, never shrunk)
-    sifthip::DevBuf in_img, in_rgb, base, tmp, masks, row_cnt, row_off, cand, cand_mask, cand_mm, feat, hist,
-        table, layer_consts, counters, qi8, ri8, qnorm, rconst, best, d1, d2, io_a, io_b, frame2,
-        gau_all, dog_all;  // all Gaussian / DoG levels of the current octave, level-major
+    sifthip::DevBuf in_img, in_rgb, tmp, feat, hist, table, layer_consts, gcounters, qi8, ri8, qnorm, rconst, best,
+        d1, d2, io_a, io_b, frame2, dog_all;
+    std::vector<sifthip::OctWs> lanes;  // lanes[0] runs on `stream`
+    hipEvent_t ev_start = nullptr;
     int cand_cap = 0;
     // pinned host staging
     int32_t* h_counters = nullptr;
@@ -83,22 +99,26 @@ namespace sifthip {
 bool hip_ok(sift_hip_ctx* ctx, hipError_t e, const char* what);
 int ensure(sift_hip_ctx* ctx, DevBuf& b, size_t bytes);
 int ensure_pinned(sift_hip_ctx* ctx, DevBuf& b, size_t bytes);
-void prof_begin(sift_hip_ctx* ctx, int cls);
-void prof_end(sift_hip_ctx* ctx);
+void prof_begin(sift_hip_ctx* ctx, int cls, hipStream_t st);
+void prof_end(sift_hip_ctx* ctx, hipStream_t st);
 
 struct ProfScope {
     sift_hip_ctx* c;
-    ProfScope(sift_hip_ctx* ctx, int cls) : c(ctx) { if (c->profiling) prof_begin(c, cls); }
-    ~ProfScope() { if (c->profiling) prof_end(c); }
+    hipStream_t st;
+    ProfScope(sift_hip_ctx* ctx, int cls, hipStream_t s) : c(ctx), st(s) { if (c->profiling) prof_begin(c, cls, st); }
+    ~ProfScope() { if (c->profiling) prof_end(c, st); }
 };
 
 // ---- launchers (defined next to their kernels) --------------------------------
 // pyramid.hip
-void launch_gray(sift_hip_ctx* ctx, const float* rgb, float* gray, size_t n);
-void launch_first(sift_hip_ctx* ctx, const float* src, int w, int h, float ratio, float* dst, int nw, int nh);
-// One separable blur: src -> (tmp) -> dst; if dog != nullptr also dog = prev - dst.
-void launch_blur(sift_hip_ctx* ctx, const float* src, float* tmp, float* dst, int W, int H, const float* d_taps,
-                 int K, int blur_mode, const float* prev, float* dog);
+void launch_gray(sift_hip_ctx* ctx, hipStream_t st, const float* rgb, float* gray, size_t n);
+void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, int h, float ratio, float* dst, int nw,
+                  int nh);
+// One separable blur: src -> (tmp) -> dst.
+void launch_blur(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
+                 const float* d_taps, int K, int blur_mode);
+// dog[k] = gau[k] - gau[k+1] for k < nlev-1 (only the octave_levels entry point stores DoG images)
+void launch_dog(sift_hip_ctx* ctx, hipStream_t st, const float* gau, float* dog, size_t PX, int nlev);
 // detect.hip
 struct LayerConsts {  // per DoG layer 1..intvls of one octave
     int32_t radius;       // histogram window radius r (Sift.cpp:177)
@@ -106,15 +126,14 @@ struct LayerConsts {  // per DoG layer 1..intvls of one octave
     float curr_sigma;     // currSigma (Sift.cpp:183)
     float sigma_oct;      // (float)(int)curr_sigma, what FeatAppend stores
 };
-// dog / gau: level-major images of the current octave, PX pixels per level.
-void launch_detect(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
+// ws.gau_all: level-major Gaussian images of the octave, PX pixels per level
+// (DoG values are recomputed from adjacent levels, never stored).
+void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
                    float thr, int cand_cap);
-void launch_orient(sift_hip_ctx* ctx, const float* dog, size_t PX, int W, const LayerConsts* d_lc,
-                   const float* d_table);
-void launch_emit(sift_hip_ctx* ctx, float curr_size, const LayerConsts* d_lc, int feat_cap);
-// descriptor.hip
-// max_window: sample count (2R+1)^2 of the octave's largest descriptor window
-void launch_descr(sift_hip_ctx* ctx, const float* gau, size_t PX, int W, int H, const float* d_cs, int feat_cap,
+void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table);
+void launch_emit(sift_hip_ctx* ctx, OctWs& ws, float curr_size, const LayerConsts* d_lc, int feat_cap);
+// descriptor.hip; max_window: sample count (2R+1)^2 of the octave's largest descriptor window
+void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const float* d_cs, int feat_cap,
                   float* d_hist, int max_window);
 // match.hip
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,

@@ -201,7 +201,7 @@ int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r,
     if ((rc = ensure(ctx, ctx->ri8, (size_t)nr_pad * 128))) return rc;
     if ((rc = ensure(ctx, ctx->qnorm, (size_t)nq_pad * 4))) return rc;
     if ((rc = ensure(ctx, ctx->rconst, (size_t)nr_pad * 4))) return rc;
-    ProfScope ps(ctx, SIFT_HIP_K_MATCH);
+    ProfScope ps(ctx, SIFT_HIP_K_MATCH, ctx->stream);
     hipLaunchKernelGGL(match_prep_kernel, dim3((nq_pad * 8 + 255) / 256), dim3(256), 0, ctx->stream, d_q, nq, nq_pad,
                        (int8_t*)ctx->qi8.p, (int*)ctx->qnorm.p, 0);
     hipLaunchKernelGGL(match_prep_kernel, dim3((nr_pad * 8 + 255) / 256), dim3(256), 0, ctx->stream, d_r, nr, nr_pad,

@@ -1,5 +1,6 @@
 // Scale-space kernels for gfx950: gray conversion, bilinear octave resample,
-// separable Gaussian blur (row pass, column pass with fused DoG write).
+// separable Gaussian blur (row pass, column pass).  DoG layers are not stored by
+// the extract path; the detector subtracts adjacent levels on the fly.
 //
 // Numerics follow the reference exactly in blur_mode 0: every tap is a float
 // product rounded to float, accumulated in double in ascending tap order, and the
@@ -26,9 +27,9 @@ __global__ __launch_bounds__(256) void gray_kernel(const float* __restrict__ rgb
     gray[i] = (float)v;
 }
 
-void launch_gray(sift_hip_ctx* ctx, const float* rgb, float* gray, size_t n) {
-    ProfScope ps(ctx, SIFT_HIP_K_GRAY);
-    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rgb, gray, n);
+void launch_gray(sift_hip_ctx* ctx, hipStream_t st, const float* rgb, float* gray, size_t n) {
+    ProfScope ps(ctx, SIFT_HIP_K_GRAY, st);
+    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rgb, gray, n);
 }
 
 // ---- Scaling::first + Scaling::bilinear, imglib.cpp:203-252 ----------------------
@@ -65,10 +66,11 @@ __global__ __launch_bounds__(256) void first_kernel(const float* __restrict__ sr
     dst[(size_t)j * nw + i] = AB * dy2 + CD * dy1;
 }
 
-void launch_first(sift_hip_ctx* ctx, const float* src, int w, int h, float ratio, float* dst, int nw, int nh) {
-    ProfScope ps(ctx, SIFT_HIP_K_RESAMPLE);
+void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, int h, float ratio, float* dst, int nw,
+                  int nh) {
+    ProfScope ps(ctx, SIFT_HIP_K_RESAMPLE, st);
     dim3 grid((nw + 63) / 64, (nh + 3) / 4);
-    hipLaunchKernelGGL(first_kernel, grid, dim3(256), 0, ctx->stream, src, w, h, ratio, dst, nw, nh);
+    hipLaunchKernelGGL(first_kernel, grid, dim3(256), 0, st, src, w, h, ratio, dst, nw, nh);
 }
 
 // ---- separable blur ----------------------------------------------------------------
@@ -148,11 +150,9 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
 }
 
 // Column pass: a 256-thread workgroup owns 64 columns x TH rows; LDS holds the
-// TH + K - 1 input rows.  Each wave takes P-row chunks.  With DOG the kernel also
-// writes dog = prev - out (Sift.cpp:161-168), prev being the previous level.
-template <typename ACC, bool DOG>
-__global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                       const float* __restrict__ prev, float* __restrict__ dog, int W,
+// TH + K - 1 input rows.  Each wave takes P-row chunks.
+template <typename ACC>
+__global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
                                                        int H, const float* __restrict__ taps, int K, int TH) {
     extern __shared__ float s[];
     const int lane = threadIdx.x & 63;
@@ -201,10 +201,7 @@ __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__
             for (int p = 0; p < P; p++) {
                 const int y = y0 + c + p;
                 if (y < H) {
-                    const float v = (float)acc[p];
-                    const size_t idx = (size_t)y * W + x;
-                    out[idx] = v;
-                    if (DOG) dog[idx] = prev[idx] - v;
+                    out[(size_t)y * W + x] = (float)acc[p];
                 }
             }
         }
@@ -213,9 +210,8 @@ __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__
 
 // Column pass for kernels too long for an LDS tile: the window slides over rows
 // read straight from global memory (L1/L2 serve the overlap between row chunks).
-template <typename ACC, bool DOG>
+template <typename ACC>
 __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                              const float* __restrict__ prev, float* __restrict__ dog,
                                                               int W, int H, const float* __restrict__ taps, int K) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -258,59 +254,65 @@ __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __res
     for (int p = 0; p < P; p++) {
         const int y = yb + p;
         if (y < H) {
-            const float v = (float)acc[p];
-            const size_t idx = (size_t)y * W + x;
-            out[idx] = v;
-            if (DOG) dog[idx] = prev[idx] - v;
+            out[(size_t)y * W + x] = (float)acc[p];
         }
     }
 }
 
-constexpr int kMaxColLds = 120 * 1024;  // largest LDS tile the column pass may request
+constexpr int kMaxColLds = 64 * 1024;  // largest LDS tile the column pass may request
 
 template <typename ACC>
-static void launch_blur_t(sift_hip_ctx* ctx, const float* src, float* tmp, float* dst, int W, int H,
-                          const float* d_taps, int K, const float* prev, float* dog) {
+static void launch_blur_t(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
+                          const float* d_taps, int K) {
     {
-        ProfScope ps(ctx, SIFT_HIP_K_BLUR_ROW);
+        ProfScope ps(ctx, SIFT_HIP_K_BLUR_ROW, st);
         const int n_in = 64 * P + K - 1 + P;
         const size_t lds = (size_t)(n_in + (n_in >> 3) + 1) * sizeof(float);
         dim3 grid((W + 64 * P - 1) / (64 * P), H);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC>), grid, dim3(64), lds, ctx->stream, src, tmp, W, H,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC>), grid, dim3(64), lds, st, src, tmp, W, H,
                            d_taps, K);
     }
     {
-        ProfScope ps(ctx, SIFT_HIP_K_BLUR_COL);
+        ProfScope ps(ctx, SIFT_HIP_K_BLUR_COL, st);
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
         int TH = 128;
         while (TH > 32 && (size_t)(TH + K - 1 + P) * 256 > 48 * 1024) TH >>= 1;
         const size_t lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
         if (lds <= (size_t)kMaxColLds) {
             dim3 grid((W + 63) / 64, (H + TH - 1) / TH);
-            if (dog)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC, true>), grid, dim3(256), lds, ctx->stream, tmp,
-                                   dst, prev, dog, W, H, d_taps, K, TH);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC, false>), grid, dim3(256), lds, ctx->stream,
-                                   tmp, dst, prev, dog, W, H, d_taps, K, TH);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC>), grid, dim3(256), lds, st, tmp, dst, W, H,
+                               d_taps, K, TH);
         } else {
             dim3 grid((W + 63) / 64, (H + 4 * P - 1) / (4 * P));
-            if (dog)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_global_kernel<ACC, true>), grid, dim3(256), 0, ctx->stream,
-                                   tmp, dst, prev, dog, W, H, d_taps, K);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_global_kernel<ACC, false>), grid, dim3(256), 0,
-                                   ctx->stream, tmp, dst, prev, dog, W, H, d_taps, K);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_global_kernel<ACC>), grid, dim3(256), 0, st, tmp, dst,
+                               W, H, d_taps, K);
         }
     }
 }
 
-void launch_blur(sift_hip_ctx* ctx, const float* src, float* tmp, float* dst, int W, int H, const float* d_taps, int K,
-                 int blur_mode, const float* prev, float* dog) {
+void launch_blur(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
+                 const float* d_taps, int K, int blur_mode) {
     if (blur_mode == 1)
-        launch_blur_t<float>(ctx, src, tmp, dst, W, H, d_taps, K, prev, dog);
+        launch_blur_t<float>(ctx, st, src, tmp, dst, W, H, d_taps, K);
     else
-        launch_blur_t<double>(ctx, src, tmp, dst, W, H, d_taps, K, prev, dog);
+        launch_blur_t<double>(ctx, st, src, tmp, dst, W, H, d_taps, K);
+}
+
+// DoG images for callers that want them stored (Sift.cpp:161-168): dog[k] = gau[k] - gau[k+1].
+__global__ __launch_bounds__(256) void dog_kernel(const float* __restrict__ gau, float* __restrict__ dog, size_t PX,
+                                                  int nlev) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= PX) return;
+    float a = gau[i];
+    for (int k = 0; k + 1 < nlev; k++) {
+        const float b = gau[(size_t)(k + 1) * PX + i];
+        dog[(size_t)k * PX + i] = a - b;
+        a = b;
+    }
+}
+
+void launch_dog(sift_hip_ctx* ctx, hipStream_t st, const float* gau, float* dog, size_t PX, int nlev) {
+    hipLaunchKernelGGL(dog_kernel, dim3((unsigned)((PX + 255) / 256)), dim3(256), 0, st, gau, dog, PX, nlev);
 }
 
 }  // namespace sifthip
