@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -267,7 +268,7 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         return SIFT_HIP_ERR_HIP;
     hipEventRecord(ctx->ev_start, ctx->stream);
     const float thr = (float)((double)prm.dx_thr / 2.0);
-    const bool serial = ctx->profiling;
+    const bool serial = ctx->profiling || ctx->force_serial;
     for (int oi = 0; oi < noct; oi++) {
         OctWs& ws = ctx->lanes[oi];
         const hipStream_t lane_stream = ws.stream;
@@ -369,6 +370,8 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     sift_hip_ctx* ctx = new (std::nothrow) sift_hip_ctx();
     if (!ctx) return SIFT_HIP_ERR_NOMEM;
     ctx->device = device;
+    // SIFT_HIP_SERIAL=1: all octaves on one stream (clean per-kernel durations under a tracer)
+    if (const char* e = std::getenv("SIFT_HIP_SERIAL")) ctx->force_serial = (e[0] == '1');
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||

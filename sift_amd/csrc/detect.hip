@@ -1,6 +1,6 @@
 // Keypoint detection for one octave on gfx950:
-//   detect_rows   3x3x3 extremum + contrast + edge test, one workgroup per image
-//                 row (all DoG layers); wavefront ballots become 64-pixel mask words
+//   detect_tile   3x3x3 extremum + contrast + edge test on LDS-staged DoG tiles
+//                 (all layers); wavefront ballots become 64-pixel mask words
 //   scan_rows     exclusive prefix sum of the per-row counts (one workgroup)
 //   expand_rows   mask words -> ordered candidate list (wave prefix sums)
 //   orient        36-bin orientation histogram, one wavefront per candidate
@@ -14,37 +14,37 @@
 namespace sifthip {
 
 // The DoG layers are never stored: dog[k] = gau[k] - gau[k+1] (Sift.cpp:161-168) is
-// one float subtraction, recomputed wherever a DoG value is needed.  The detector
-// streams Gaussian levels 1..intvls+1 once; only pixels that pass the contrast
-// test (a few percent) touch their 3x3x3 neighbourhood.
-__device__ __forceinline__ float dogv(const float* __restrict__ gau, size_t PX, int k, size_t q) {
-    return gau[(size_t)k * PX + q] - gau[(size_t)(k + 1) * PX + q];
-}
+// one float subtraction.  A workgroup stages the DoG values of a 64 x DET_TR pixel
+// tile (plus a one-pixel halo) for all intvls+2 layers in LDS, reading each
+// Gaussian level once, then tests its pixels from LDS.
+constexpr int DET_TR = 16;             // tile rows
+constexpr int DET_LW = 66;             // tile width incl. halo
+constexpr int DET_LH = DET_TR + 2;     // tile rows incl. halo
+constexpr int kMaxIntvls = 8;
 
 // ---- findMaxMin (Sift.cpp:86-104) + harris_corner (Sift.cpp:105-129) -------------
-// li = DoG layer index (1..intvls), v = dog[li] at (y, x), already past |v| > thr.
-__device__ __forceinline__ bool is_keypoint(const float* __restrict__ gau, size_t PX, int li, int W, int y, int x,
-                                            float v, float rad) {
-    const size_t c = (size_t)y * W + x;
-    float cur[9];
+// d = LDS DoG tile of layer li centred on the pixel (row stride DET_LW, layer
+// stride DET_LH*DET_LW); v = its value, already past |v| > thr.
+__device__ __forceinline__ bool is_keypoint(const float* d, float v, float rad) {
+    constexpr int LS = DET_LH * DET_LW;
+    // "no neighbour is larger" (v > 0) / "no neighbour is smaller" (v < 0), ties
+    // allowed, as max/min over the 27 values (the centre itself changes nothing)
+    float mx = v, mn = v;
 #pragma unroll
     for (int k = -1; k <= 1; k++) {
 #pragma unroll
         for (int j = -1; j <= 1; j++) {
-#pragma unroll
-            for (int i = -1; i <= 1; i++) {
-                const float nb = dogv(gau, PX, li + k, c + (ptrdiff_t)j * W + i);
-                if (k == 0) cur[(j + 1) * 3 + (i + 1)] = nb;
-                if (v > 0.f && v < nb) return false;
-                if (v < 0.f && v > nb) return false;
-            }
+            const float a = d[k * LS + j * DET_LW - 1], b = d[k * LS + j * DET_LW], c = d[k * LS + j * DET_LW + 1];
+            mx = fmaxf(mx, fmaxf(a, fmaxf(b, c)));
+            mn = fminf(mn, fminf(a, fminf(b, c)));
         }
     }
+    if (v > 0.f ? (mx > v) : (mn < v)) return false;
     // edge test; the "r" of the reference call is the histogram radius
     const float thre = ((rad + 1.f) * (rad + 1.f)) / rad;
-    const float Dxx = 2.f * v - cur[3] - cur[5];
-    const float Dyy = 2.f * v - cur[1] - cur[7];
-    float Dxy = cur[8] + cur[0] - cur[2] - cur[6];
+    const float Dxx = 2.f * v - d[-1] - d[1];
+    const float Dyy = 2.f * v - d[-DET_LW] - d[DET_LW];
+    float Dxy = d[DET_LW + 1] + d[-DET_LW - 1] - d[-DET_LW + 1] - d[DET_LW - 1];
     Dxy /= 4.f;
     const float Tr = Dxx + Dyy;
     const float Det = Dxx * Dyy - Dxy * Dxy;
@@ -52,48 +52,48 @@ __device__ __forceinline__ bool is_keypoint(const float* __restrict__ gau, size_
     return val < thre;
 }
 
-// grid.x = H image rows; each workgroup handles its row for every DoG layer.
-// Writes every mask word (zeros included) and the per-(layer,row) counts.
-constexpr int kMaxIntvls = 8;
-__global__ __launch_bounds__(256) void detect_rows_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
+// grid = (ceil(W/64), ceil(H/DET_TR)).  Writes every mask word of its tile (zeros
+// included) and adds the per-(layer,row) counts into row_cnt (zeroed beforehand).
+__global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
                                                           int intvls, const LayerConsts* __restrict__ lc, float thr,
                                                           int WW, unsigned long long* __restrict__ masks,
                                                           int* __restrict__ row_cnt) {
-    __shared__ int s_cnt[kMaxIntvls][4];
-    const int y = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int cnt[kMaxIntvls];
-#pragma unroll
-    for (int l = 0; l < kMaxIntvls; l++) cnt[l] = 0;
-    for (int xb = 0; xb < WW * 64; xb += 256) {
-        const int x = xb + threadIdx.x;
-        const size_t c = (size_t)y * W + min(x, W - 1);
-        float ga = gau[PX + c];  // level 1
-#pragma unroll
-        for (int l = 0; l < kMaxIntvls; l++) {
-            if (l < intvls) {
-                const float gb = gau[(size_t)(l + 2) * PX + c];
-                const float v = ga - gb;  // dog[l+1]
-                ga = gb;
-                const int rad = lc[l].radius;
-                // scan bounds of Sift.cpp:178-179: r+1 <= y < H-r-1, r+1 <= x < W-r-1
-                bool hit = (H >= 2 * rad + 3) && (W >= 2 * rad + 3) && y >= rad + 1 && y < H - rad - 1 &&
-                           x >= rad + 1 && x < W - rad - 1 && (fabsf(v) > thr);
-                if (hit) hit = is_keypoint(gau, PX, l + 1, W, y, x, v, (float)rad);
-                const unsigned long long m = __ballot(hit);
-                const int word = (xb >> 6) + wave;
-                if (lane == 0 && word < WW) masks[((size_t)l * H + y) * WW + word] = m;
-                cnt[l] += __popcll(m);
-            }
+    extern __shared__ float s_dog[];  // [intvls+2][DET_LH][DET_LW]
+    constexpr int LS = DET_LH * DET_LW;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DET_TR;
+    const int nlay = intvls + 2;
+    for (int t = threadIdx.x; t < LS; t += 256) {
+        const int ty = t / DET_LW, tx = t - ty * DET_LW;
+        const int gx = min(max(x0 + tx - 1, 0), W - 1);
+        const int gy = min(max(y0 + ty - 1, 0), H - 1);
+        const size_t q = (size_t)gy * W + gx;
+        float a = gau[q];
+        for (int k = 0; k < nlay; k++) {
+            const float b = gau[(size_t)(k + 1) * PX + q];
+            s_dog[k * LS + t] = a - b;
+            a = b;
         }
     }
-#pragma unroll
-    for (int l = 0; l < kMaxIntvls; l++)
-        if (l < intvls && lane == 0) s_cnt[l][wave] = cnt[l];
     __syncthreads();
-    if (threadIdx.x < intvls) {
-        const int l = threadIdx.x;
-        row_cnt[l * H + y] = s_cnt[l][0] + s_cnt[l][1] + s_cnt[l][2] + s_cnt[l][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = x0 + lane;
+    for (int ry = wave; ry < DET_TR; ry += 4) {
+        const int y = y0 + ry;
+        if (y >= H) break;  // wave-uniform
+        for (int l = 0; l < intvls; l++) {
+            const int rad = lc[l].radius;
+            const float* d = s_dog + (l + 1) * LS + (ry + 1) * DET_LW + (lane + 1);
+            const float v = *d;
+            // scan bounds of Sift.cpp:178-179: r+1 <= y < H-r-1, r+1 <= x < W-r-1
+            bool hit = (H >= 2 * rad + 3) && (W >= 2 * rad + 3) && y >= rad + 1 && y < H - rad - 1 && x >= rad + 1 &&
+                       x < W - rad - 1 && (fabsf(v) > thr);
+            if (hit) hit = is_keypoint(d, v, (float)rad);
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) {
+                masks[((size_t)l * H + y) * WW + blockIdx.x] = m;
+                if (m) atomicAdd(&row_cnt[l * H + y], __popcll(m));
+            }
+        }
     }
 }
 
@@ -315,8 +315,11 @@ void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
     const int nrows = intvls * H;
     {
         ProfScope ps(ctx, SIFT_HIP_K_DETECT, ws.stream);
-        hipLaunchKernelGGL(detect_rows_kernel, dim3(H), dim3(256), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H,
-                           intvls, d_lc, thr, WW, (unsigned long long*)ws.masks.p, (int*)ws.row_cnt.p);
+        hipMemsetAsync(ws.row_cnt.p, 0, (size_t)nrows * sizeof(int), ws.stream);
+        const size_t lds = (size_t)(intvls + 2) * DET_LH * DET_LW * sizeof(float);
+        hipLaunchKernelGGL(detect_tile_kernel, dim3(WW, (H + DET_TR - 1) / DET_TR), dim3(256), lds, ws.stream,
+                           (const float*)ws.gau_all.p, PX, W, H, intvls, d_lc, thr, WW,
+                           (unsigned long long*)ws.masks.p, (int*)ws.row_cnt.p);
     }
     {
         ProfScope ps(ctx, SIFT_HIP_K_COMPACT, ws.stream);

@@ -86,6 +86,7 @@ struct sift_hip_ctx {
 
     // profiling
     bool profiling = false;
+    bool force_serial = false;
     struct Ev { int cls; hipEvent_t a, b; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> free_events;
