@@ -101,8 +101,10 @@ int sift_hip_extract_batch_dev(sift_hip_ctx* ctx, const float* d_frames, int w, 
 /* Gaus::gau_matrix, imglib.cpp:127-155 (host arithmetic, no GPU work). Returns the
  * tap count, or -needed if cap is too small. */
 int sift_hip_gau_matrix(float p, int mat_len, float* taps, int cap);
-/* Gaus::GauBlur, imglib.cpp:72-118: host in -> host out, w*h floats. */
-int sift_hip_gau_blur(sift_hip_ctx* ctx, const float* in, float* out, int w, int h, float p, int blur_mode);
+/* Gaus::GauBlur, imglib.cpp:72-118: host in -> host out, w*h floats; mat_len = 0 derives the
+ * tap count from p as the reference does. */
+int sift_hip_gau_blur(sift_hip_ctx* ctx, const float* in, float* out, int w, int h, float p, int mat_len,
+                      int blur_mode);
 /* Scaling::first / ImgRaw::first, imglib.cpp:227-252: out is floor(w*ratio) x floor(h*ratio). */
 int sift_hip_first(sift_hip_ctx* ctx, const float* in, int w, int h, float ratio, float* out);
 /* ImgRaw::ConverGray, Imgraw.cpp:257-269: n RGB pixels -> n gray floats. */

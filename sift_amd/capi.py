@@ -101,7 +101,7 @@ def load_library() -> C.CDLL:
         "sift_hip_extract_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip]),
         "sift_hip_extract_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip]),
         "sift_hip_gau_matrix": (C.c_int, [C.c_float, C.c_int, fp, C.c_int]),
-        "sift_hip_gau_blur": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int]),
+        "sift_hip_gau_blur": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]),
         "sift_hip_first": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
         "sift_hip_convert_gray": (C.c_int, [vp, vp, C.c_int, vp]),
         "sift_hip_octave_levels": (C.c_int, [vp, vp, C.c_int, C.c_int, P, C.c_int, vp, vp, ip, ip]),
@@ -230,11 +230,11 @@ class SiftHip:
         return rc
 
     # ---- image ops ----------------------------------------------------------------
-    def gau_blur(self, img: np.ndarray, p: float, blur_mode: int = 0) -> np.ndarray:
+    def gau_blur(self, img: np.ndarray, p: float, blur_mode: int = 0, mat_len: int = 0) -> np.ndarray:
         img = _f32(img)
         h, w = img.shape
         out = np.empty_like(img)
-        self._check(self.lib.sift_hip_gau_blur(self.h, _ptr(img), _ptr(out), w, h, p, blur_mode))
+        self._check(self.lib.sift_hip_gau_blur(self.h, _ptr(img), _ptr(out), w, h, p, mat_len, blur_mode))
         return out
 
     def first(self, img: np.ndarray, ratio: float) -> np.ndarray:

@@ -541,11 +541,12 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
     return worst;
 }
 
-int sift_hip_gau_blur(sift_hip_ctx* ctx, const float* in, float* out, int w, int h, float p, int blur_mode) {
-    if (bad_ctx(ctx) || !in || !out || w < 1 || h < 1 || !(p > 0.f)) return SIFT_HIP_ERR_ARG;
+int sift_hip_gau_blur(sift_hip_ctx* ctx, const float* in, float* out, int w, int h, float p, int mat_len,
+                      int blur_mode) {
+    if (bad_ctx(ctx) || !in || !out || w < 1 || h < 1 || !(p > 0.f) || mat_len < 0) return SIFT_HIP_ERR_ARG;
     if (in == out) return SIFT_HIP_ERR_SAME;
     const size_t px = (size_t)w * h;
-    std::vector<float> g = gau_matrix(p, 0);
+    std::vector<float> g = gau_matrix(p, (size_t)mat_len);
     int rc;
     if ((rc = ensure(ctx, ctx->io_a, px * 4))) return rc;
     if ((rc = ensure(ctx, ctx->io_b, px * 4))) return rc;

@@ -1,0 +1,257 @@
+// Host side of the drop-in: the reference's classes over the C ABI of
+// include/sift_hip.h.  Nothing here computes pixels or distances on the CPU.
+#include "Sift.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/sift_hip.h"
+
+namespace sift_amd {
+
+static void check(sift_hip_ctx* ctx, int rc, const char* what) {
+    if (rc == SIFT_HIP_OK) return;
+    std::string msg = std::string(what) + ": " + sift_hip_strerror(rc);
+    if (ctx && sift_hip_last_error(ctx)[0]) msg += std::string(" (") + sift_hip_last_error(ctx) + ")";
+    throw std::runtime_error(msg);
+}
+
+sift_hip_ctx* default_context() {
+    static sift_hip_ctx* ctx = nullptr;
+    static std::once_flag once;
+    static int rc = SIFT_HIP_OK;
+    std::call_once(once, [] {
+        const char* e = std::getenv("SIFT_HIP_DEVICE");
+        rc = sift_hip_create(&ctx, e ? std::atoi(e) : 0);
+    });
+    check(nullptr, rc, "sift_hip_create");
+    return ctx;
+}
+
+Options& options() {
+    static Options o;
+    return o;
+}
+
+}  // namespace sift_amd
+
+using sift_amd::check;
+using sift_amd::default_context;
+
+// ---- imglib mirrors --------------------------------------------------------------
+void Gaus::GauBlur(std::vector<float>& img_gau, const std::vector<float>& img_ori, size_t width, size_t height, float p,
+                   size_t mat_len) {
+    if (&img_gau == &img_ori) throw file_same("## Erroe! in and out is same.");  // imglib.cpp:76-78
+    if (img_ori.size() < width * height) throw Size_error("GauBlur: image smaller than width*height");
+    img_gau.resize(height * width);
+    sift_hip_ctx* ctx = default_context();
+    check(ctx, sift_hip_gau_blur(ctx, img_ori.data(), img_gau.data(), (int)width, (int)height, p, (int)mat_len,
+                                 sift_amd::options().blur_mode), "sift_hip_gau_blur");
+}
+
+std::vector<float> Gaus::gau_matrix(float p, size_t mat_len) {
+    std::vector<float> g(mat_len ? mat_len + 2 : (size_t)(p * 6 + 8));
+    int n = sift_hip_gau_matrix(p, (int)mat_len, g.data(), (int)g.size());
+    if (n < 0 && n != SIFT_HIP_ERR_ARG) {
+        g.resize((size_t)-n);
+        n = sift_hip_gau_matrix(p, (int)mat_len, g.data(), (int)g.size());
+    }
+    if (n < 0) throw std::runtime_error("sift_hip_gau_matrix: invalid argument");
+    g.resize((size_t)n);
+    return g;
+}
+
+void Scaling::first(std::vector<float>& img, std::vector<float>& img_ori, size_t width, size_t height, float Ratio) {
+    const int newH = static_cast<int>(std::floor(height * Ratio));
+    const int newW = static_cast<int>(std::floor(width * Ratio));
+    if (newH < 1 || newW < 1) throw Size_error("Scaling::first: empty result");
+    img.resize((size_t)newH * newW);
+    sift_hip_ctx* ctx = default_context();
+    check(ctx, sift_hip_first(ctx, img_ori.data(), (int)width, (int)height, Ratio, img.data()), "sift_hip_first");
+}
+
+float Scaling::bilinear(const std::vector<float>& img, size_t width, float y, float x) {
+    const size_t x0 = (size_t)std::floor(x), x1 = (size_t)std::ceil(x);
+    const size_t y0 = (size_t)std::floor(y), y1 = (size_t)std::ceil(y);
+    const float dx1 = x - x0, dx2 = 1 - dx1;
+    const float dy1 = y - y0, dy2 = 1 - dy1;
+    const float A = img[y0 * width + x0], B = img[y0 * width + x1];
+    const float C = img[y1 * width + x0], D = img[y1 * width + x1];
+    const float AB = A * dx2 + B * dx1;
+    const float CD = C * dx2 + D * dx1;
+    return AB * dy2 + CD * dy1;
+}
+
+// ---- ImgRaw ------------------------------------------------------------------------
+float fastAtan2f(float dy, float dx) {
+    static const float k = (float)(180 / 3.14159265358979323846);
+    static const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k;
+    static const float p5 = 0.1555786518463281f * k, p7 = -0.04432655554792128f * k;
+    static const float eps = (float)2.2204460492503131e-016;
+    const float ax = std::fabs(dx), ay = std::fabs(dy);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (dx < 0) a = 180.f - a;
+    if (dy < 0) a = 360.f - a;
+    return a;
+}
+
+const float ImgRaw::atBilinear(float y, float x) const {
+    if (x < 0 || y < 0 || x >= width - 1 || y >= height - 1) throw Out_of_imgRange("atBilinear(x, y) out of range");
+    return Scaling::bilinear(raw_img, width, y, x);
+}
+
+ImgRaw ImgRaw::ConverGray() const {
+    if (bitCount == 24) {
+        ImgRaw gray(width, height, 8);
+        sift_hip_ctx* ctx = default_context();
+        check(ctx, sift_hip_convert_gray(ctx, raw_img.data(), (int)(width * height), gray.raw_img.data()),
+              "sift_hip_convert_gray");
+        return gray;
+    }
+    if (bitCount == 8) return *this;
+    throw Size_error("ConverGray: bitCount must be 8 or 24");
+}
+
+void ImgRaw::first(ImgRaw& tar, ImgRaw& sou, float z) {
+    Scaling::first(tar.raw_img, sou.raw_img, sou.width, sou.height, z);
+    tar.width = (uint32_t)(size_t)(sou.width * z);
+    tar.height = (uint32_t)(size_t)(sou.height * z);
+    tar.bitCount = 8;
+}
+
+void ImgRaw::gauBlur(ImgRaw& tar, ImgRaw& sou, float p) {
+    Gaus::GauBlur(tar.raw_img, sou.raw_img, sou.width, sou.height, p);
+    tar.width = sou.width;
+    tar.height = sou.height;
+    tar.bitCount = sou.bitCount;
+}
+
+// ---- Sift ----------------------------------------------------------------------------
+Sift::Sift(ImgRaw img, size_t intvls) : raw_img(std::move(img)), pyWidth(intvls + SIFT_INTVLS_DIFF) {
+    FeatStart = new Feature[1];  // the reference starts with one empty head node (Sift.cpp:52)
+    FeatEnd = FeatStart;
+}
+
+Sift::~Sift() { delete[] FeatStart; }
+
+void Sift::pyramid() {
+    if (raw_img.bitCount != 8 && raw_img.bitCount != 24) throw Size_error("Sift::pyramid: bitCount must be 8 or 24");
+    if (raw_img.raw_img.size() < (size_t)raw_img.width * raw_img.height * (raw_img.bitCount / 8))
+        throw Size_error("Sift::pyramid: image buffer smaller than width*height");
+    sift_hip_ctx* ctx = default_context();
+    sift_hip_params prm;
+    sift_hip_default_params(&prm);
+    prm.intvls = (int)pyWidth - SIFT_INTVLS_DIFF;
+    prm.octaves = sift_amd::options().octaves;
+    prm.subpixel = sift_amd::options().subpixel;
+    prm.blur_mode = sift_amd::options().blur_mode;
+    int cap = 1 << 15, n = 0;
+    std::vector<sift_hip_feat> buf;
+    for (;;) {
+        buf.resize((size_t)cap);
+        const int rc = sift_hip_extract(ctx, raw_img.raw_img.data(), (int)raw_img.width, (int)raw_img.height,
+                                        raw_img.bitCount / 8, &prm, buf.data(), cap, &n, nullptr);
+        if (rc == SIFT_HIP_ERR_NOSPC) {
+            cap = n;
+            continue;
+        }
+        check(ctx, rc, "sift_hip_extract");
+        break;
+    }
+    // the reference copies its linked list into new Feature[feaNum] (Sift.cpp:207-224)
+    Feature* arr = new Feature[n > 0 ? n : 1];
+    for (int i = 0; i < n; i++) {
+        const sift_hip_feat& s = buf[(size_t)i];
+        Feature& f = arr[i];
+        f.size = s.size;
+        f.kai = s.kai;
+        f.sigmaOCT = s.sigmaOCT;
+        f.x = s.x;
+        f.y = s.y;
+        f.mm = s.mm;
+        f.sita = s.sita;
+        for (int k = 0; k < 128; k++) f.descr[k] = (float)s.descr[k];
+        f.d = 128;
+    }
+    delete[] FeatStart;
+    FeatStart = arr;
+    FeatEnd = arr + (n > 0 ? n - 1 : 0);
+    feaNum = (size_t)n;
+}
+
+// ---- Stitching -------------------------------------------------------------------------
+Stitching::Stitching(const Sift& desc1, const Sift& desc2)
+    : feat1(desc1.FeatStart), feat2(desc2.FeatStart), feat1_Count(desc1.feaNum), feat2_Count(desc2.feaNum) {
+    img1 = desc1.raw_img;
+    img2 = desc2.raw_img;
+    Width = img1.width + img2.width;
+    Height = img1.height;
+    // side-by-side canvas the reference keeps for its debug drawings (Sift.cpp:502-517)
+    if (img1.bitCount == 24 && img2.bitCount == 24 && img1.height == img2.height) {
+        stackImg.resize(img1.width + img2.width, img1.height, 24);
+        for (size_t j = 0; j < img1.height; j++) {
+            std::memcpy(&stackImg[(j * stackImg.width) * 3], &img1[(j * img1.width) * 3], (size_t)img1.width * 3 * 4);
+            std::memcpy(&stackImg[(j * stackImg.width + img1.width) * 3], &img2[(j * img2.width) * 3],
+                        (size_t)img2.width * 3 * 4);
+        }
+    }
+}
+
+size_t Stitching::Match(float matchTh) {
+    std::vector<uint8_t> q(feat2_Count * 128), r(feat1_Count * 128);
+    auto pack = [](const Feature* f, size_t n, std::vector<uint8_t>& out) {
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 128; k++) {
+                const float v = f[i].descr[k];  // integer-valued, 0..255 (Sift.cpp:416-420)
+                out[i * 128 + k] = (uint8_t)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
+            }
+    };
+    pack(feat2, feat2_Count, q);
+    pack(feat1, feat1_Count, r);
+    std::vector<int32_t> best(feat2_Count);
+    sift_hip_ctx* ctx = default_context();
+    check(ctx, sift_hip_match_u8(ctx, q.data(), (int)feat2_Count, r.data(), (int)feat1_Count, matchTh,
+                                 sift_amd::options().ratio_form, best.data(), nullptr, nullptr), "sift_hip_match_u8");
+    size_t accepted = 0;
+    for (size_t i = 0; i < feat2_Count; i++) {
+        if (best[i] >= 0) {
+            feat2[i].fwd_match = &feat1[best[i]];  // Sift.cpp:577
+            accepted++;
+        } else if (sift_amd::options().ratio_form == 0) {
+            feat2[i].fwd_match = nullptr;
+        }
+    }
+    return accepted;
+}
+
+#ifdef SIFT_AMD_WITH_CONSUMERS
+// The reference's own RANSAC and blender (ransac/xform.hpp:4-6, stitch/Blend.hpp:15).
+extern std::vector<float> ransac_xform(Feature* features, int n, int m, float p_badxform, float err_tol,
+                                       Feature*** inliers, int& n_in);
+void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::vector<float>& HomogMat,
+              const Feature* const* RANSAC_feat, int RANSAC_num);
+#endif
+
+void Stitching::Check(float matchTh) {
+    Match(matchTh);
+#ifdef SIFT_AMD_WITH_CONSUMERS
+    Feature** RANSAC_feat = nullptr;
+    int RANSAC_num = 0;
+    const std::vector<float> HomogMat = ransac_xform(feat2, (int)feat2_Count, 4, 0.005f, 3.f, &RANSAC_feat, RANSAC_num);
+    ImgRaw dst;
+    blen2img(img1, img2, dst, HomogMat, RANSAC_feat, RANSAC_num);
+#endif
+}

@@ -1,0 +1,93 @@
+// Drop-in for the reference's Sift/Sift.hpp: same macros, same `Sift` and
+// `Stitching` classes with the same public members, so StitchImg
+// (Sift_main.cpp:31-55), ransac_xform (ransac/xform.cpp:37) and blen2img
+// (stitch/Blend.cpp:898) keep compiling against it.  Sift::pyramid() and the
+// matcher inside Stitching::Check() run on the GPU through include/sift_hip.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "Imgraw.hpp"
+#include "imagedata.hpp"
+#include "imglib.hpp"
+
+#define SIFT_INTVLS 3
+#define SIFT_INTVLS_DIFF 3
+#define SIFT_GauSigma 1.6f
+#define SIFT_Dx 0.03f
+#define SIFT_DESCR_SCL_FCTR 3.f
+#define SIFT_DESCR_HIST_RADIUS 4
+#define SIFT_DESCR_HIST_BINS 8
+#define SIFT_DESCR_MAG_THR 0.2
+#define SIFT_INT_DESCR_FCTR 512.0
+#define SIFT_CURV_THR 10
+#define SIFT_MAX_INTERP_STEPS 5
+#define SIFT_IMG_BORDER 5
+#define SIFT_CONTR_THR 0.05
+#define KDTREE_BBF_MAX_NN_CHKS 200
+#define NN_SQ_DIST_RATIO_THR 0.4
+
+struct sift_hip_ctx;
+
+namespace sift_amd {
+// Process-wide GPU context used by the classes below (device = $SIFT_HIP_DEVICE or 0).
+// Throws std::runtime_error when the library cannot get a gfx950 device.
+sift_hip_ctx* default_context();
+// Overrides for parameters the reference fixes at compile time.
+struct Options {
+    int octaves = 0;    // 0 = reference's automatic count (Sift.cpp:130-139)
+    int subpixel = 0;   // 1 = Lowe refinement (matrix.hpp:140-196), off in the reference
+    int blur_mode = 0;  // 0 = exact reference arithmetic
+    int ratio_form = 0; // 0 = d0 < d1*th (Sift.cpp:576), 1 = (d0/d1) < th (Sift.cpp:563)
+};
+Options& options();
+}  // namespace sift_amd
+
+class Size_error : public std::runtime_error {
+public:
+    explicit Size_error(const std::string& str) : std::runtime_error(str) {}
+};
+class Out_of_imgRange : public std::runtime_error {
+public:
+    explicit Out_of_imgRange(const std::string& str) : std::runtime_error(str) {}
+};
+
+class Sift {
+public:
+    Sift(ImgRaw img, size_t intvls = SIFT_INTVLS);
+    ~Sift();
+    Sift(const Sift&) = delete;
+    Sift& operator=(const Sift&) = delete;
+    // Scale space, detection, orientation and descriptors of raw_img; fills
+    // FeatStart[0..feaNum) in the reference's order.  Throws std::runtime_error
+    // if the GPU path fails.
+    void pyramid();
+
+public:
+    ImgRaw raw_img;
+    size_t pyWidth = 3 + 2 + 1;
+    std::vector<std::vector<ImgRaw>> pyrs;      // never filled (as in the reference)
+    std::vector<std::vector<ImgRaw>> pyrs_dog;  // never filled
+    Feature* FeatStart;  // contiguous Feature[feaNum] after pyramid(); owned
+    Feature* FeatEnd;
+    size_t feaNum = 0;
+};
+
+class Stitching {
+public:
+    Stitching(const Sift& desc1, const Sift& desc2);
+    // Sift.cpp:669-702.  Matching (the part on the GPU path) always runs:
+    // queries = image-2 features, references = image-1 features, result in
+    // feat2[i].fwd_match.  RANSAC and blending are the reference's own code; they
+    // are called only when this file is built with SIFT_AMD_WITH_CONSUMERS.
+    void Check(float matchTh = NN_SQ_DIST_RATIO_THR);
+    // The matching step of Check() alone; returns the number of accepted matches.
+    size_t Match(float matchTh = NN_SQ_DIST_RATIO_THR);
+
+private:
+    Feature *feat1, *feat2;
+    size_t Width, Height;
+    ImgRaw stackImg;
+    ImgRaw img1, img2;
+    size_t feat1_Count, feat2_Count;
+};

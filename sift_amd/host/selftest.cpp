@@ -1,0 +1,81 @@
+// Exercises the drop-in C++ classes the way the reference's StitchImg does
+// (Sift_main.cpp:31-55): two images -> Sift::pyramid() each -> Stitching::Check.
+//   selftest <in.bin> <out.bin> [matchTh]
+// in.bin : int32 w, h, channels; then two images of w*h*channels float32
+// out.bin: int32 n1, n2; n1 + n2 records {float size; int kai; float sigmaOCT;
+//          int x, y; float mm; int sita; uint8 descr[128]}; then n2 int32 match
+//          indices into image 1's features (-1 = none)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "Sift.hpp"
+
+#pragma pack(push, 1)
+struct Rec {
+    float size;
+    int32_t kai;
+    float sigmaOCT;
+    int32_t x, y;
+    float mm;
+    int32_t sita;
+    uint8_t descr[128];
+};
+#pragma pack(pop)
+
+static void dump(FILE* f, const Sift& s) {
+    for (size_t i = 0; i < s.feaNum; i++) {
+        const Feature& a = s.FeatStart[i];
+        Rec r;
+        r.size = a.size; r.kai = a.kai; r.sigmaOCT = a.sigmaOCT; r.x = a.x; r.y = a.y; r.mm = a.mm; r.sita = a.sita;
+        for (int k = 0; k < 128; k++) r.descr[k] = (uint8_t)a.descr[k];
+        fwrite(&r, sizeof r, 1, f);
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: selftest in.bin out.bin [matchTh]\n"); return 2; }
+    const float th = argc > 3 ? (float)atof(argv[3]) : 0.5f;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("open input"); return 2; }
+    int32_t hdr[3];
+    if (fread(hdr, 4, 3, f) != 3) return 2;
+    const int w = hdr[0], h = hdr[1], ch = hdr[2];
+    const size_t n = (size_t)w * h * ch;
+    std::vector<float> a(n), b(n);
+    if (fread(a.data(), 4, n, f) != n || fread(b.data(), 4, n, f) != n) return 2;
+    fclose(f);
+    try {
+        ImgRaw img1(a, w, h, (uint16_t)(8 * ch)), img2(b, w, h, (uint16_t)(8 * ch));
+        Sift fea1(img1);
+        fea1.pyramid();
+        Sift fea2(img2);
+        fea2.pyramid();
+        Stitching match(fea1, fea2);
+        match.Check(th);
+        FILE* o = fopen(argv[2], "wb");
+        if (!o) { perror("open output"); return 2; }
+        const int32_t cnt[2] = {(int32_t)fea1.feaNum, (int32_t)fea2.feaNum};
+        fwrite(cnt, 4, 2, o);
+        dump(o, fea1);
+        dump(o, fea2);
+        size_t matched = 0;
+        for (size_t i = 0; i < fea2.feaNum; i++) {
+            const Feature* m = fea2.FeatStart[i].fwd_match;
+            const int32_t idx = m ? (int32_t)(m - fea1.FeatStart) : -1;
+            matched += m != nullptr;
+            fwrite(&idx, 4, 1, o);
+        }
+        fclose(o);
+        // the image-op mirrors: blur into the same vector must throw file_same
+        bool threw = false;
+        try { Gaus::GauBlur(img1.raw_img, img1.raw_img, w, h, 1.6f); } catch (const file_same&) { threw = true; }
+        printf("{\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s}\n", fea1.feaNum, fea2.feaNum, matched,
+               threw ? "true" : "false");
+    } catch (const std::exception& e) {
+        fprintf(stderr, "selftest failed: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,60 @@
+"""GPU test of the C++ drop-in classes (sift_amd/host): Sift::pyramid() and
+Stitching::Check() driven the way the reference's StitchImg drives them."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import sift_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "sift_amd", "host", "selftest")
+
+
+def run_selftest(tmp_path, a, b, th):
+    h, w = a.shape[:2]
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(np.array([w, h, ch], np.int32).tobytes())
+        f.write(np.ascontiguousarray(a, np.float32).tobytes())
+        f.write(np.ascontiguousarray(b, np.float32).tobytes())
+    res = subprocess.run([EXE, str(inp), str(outp), str(th)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    raw = open(outp, "rb").read()
+    n1, n2 = np.frombuffer(raw[:8], np.int32)
+    f1 = np.frombuffer(raw[8: 8 + 156 * n1], sift_amd.FEAT_DTYPE)
+    f2 = np.frombuffer(raw[8 + 156 * n1: 8 + 156 * (n1 + n2)], sift_amd.FEAT_DTYPE)
+    m = np.frombuffer(raw[8 + 156 * (n1 + n2):], np.int32)
+    return info, f1, f2, m
+
+
+def test_cpp_classes_equal_c_abi_and_oracle(tmp_path, sift, oracle):
+    assert os.path.exists(EXE), "build with __graft_entry__.build()"
+    a = sift_amd.blob_image(256, 192, seed=1)
+    b = sift_amd.blob_image(256, 192, seed=1, shift_x=-8)
+    info, f1, f2, m = run_selftest(tmp_path, a, b, 0.5)
+    assert info["file_same"] is True
+    fo, _ = oracle.extract(a)
+    assert len(f1) == len(fo) and np.array_equal(f1["x"], fo["x"]) and np.array_equal(f1["sita"], fo["sita"])
+    fa, _ = sift.extract(a)
+    fb, _ = sift.extract(b)
+    assert np.array_equal(f1["descr"], fa["descr"]) and np.array_equal(f2["descr"], fb["descr"])
+    # Check(): queries = image 2, references = image 1 (Sift.cpp:674), live acceptance form
+    bo, _, _ = oracle.match_u8(fb["descr"], fa["descr"], 0.5, 0)
+    assert np.array_equal(m, bo)
+    assert info["matched"] == int((bo >= 0).sum()) > 20
+
+
+def test_cpp_classes_rgb_input(tmp_path, oracle):
+    g = sift_amd.blob_image(192, 128, seed=4)
+    rgb = np.stack([g, g * np.float32(0.9), g * np.float32(0.8)], axis=-1)
+    info, f1, f2, m = run_selftest(tmp_path, rgb, rgb, 0.5)
+    fo, _ = oracle.extract(oracle.convert_gray(rgb))
+    assert len(f1) == len(fo) and np.array_equal(f1["y"], fo["y"])
+    # identical images: every feature's nearest neighbour is itself at distance 0
+    assert info["n1"] == info["n2"]

@@ -1,0 +1,140 @@
+"""CPU tests: the oracle against the committed golden vectors.
+
+imglib_ref.npz was produced by the reference's own imglib.cpp object code, so
+these comparisons pin the oracle's Gaus::gau_matrix / Gaus::GauBlur /
+Scaling::first restatement to the reference bit for bit.  oracle_extract.npz was
+produced by the oracle itself (Sift.cpp / Imgraw.cpp do not build here): those
+checks guard against regressions only -- parity with the reference for
+detection, orientation, descriptors and fastAtan2f is UNPINNED.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.oracle_lib import REF_SO, Oracle, Reference
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle()
+
+
+def test_taps_match_reference_bits(orc):
+    z = np.load(os.path.join(G, "imglib_ref.npz"))
+    for i, (p, ml) in enumerate(zip(z["tap_p"], z["tap_len"])):
+        want = z["taps"][z["tap_off"][i]: z["tap_off"][i + 1]]
+        got = orc.gau_matrix(float(p), int(ml))
+        assert got.shape == want.shape, (p, ml)
+        assert np.array_equal(bits(got), bits(want)), (p, ml)
+
+
+def test_tap_lengths_are_the_survey_table(orc):
+    # kernel length = (int)round(6p+1) | 1, imglib.cpp:132
+    lens = [len(orc.gau_matrix(float(np.float32(1.6) * np.float32(np.sqrt(np.float32(2.0))) ** i), 0)) for i in range(6)]
+    assert lens == [11, 15, 21, 29, 39, 55]
+
+
+def test_blur_matches_reference_bits(orc):
+    z = np.load(os.path.join(G, "imglib_ref.npz"))
+    for k in (0, 1):
+        for j, p in enumerate(z["blur_p"]):
+            got = orc.gau_blur(z[f"blur_in{k}"], float(p))
+            assert np.array_equal(bits(got), bits(z[f"blur_out{k}"][j])), (k, p)
+
+
+def test_first_matches_reference_bits(orc):
+    z = np.load(os.path.join(G, "imglib_ref.npz"))
+    for i, ratio in enumerate(z["first_ratio"]):
+        got = orc.first(z["first_in"], float(ratio))
+        assert np.array_equal(bits(got), bits(z[f"first_out{i}"])), ratio
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref only exists where the reference is mounted")
+def test_oracle_equals_live_reference_objects(orc):
+    ref = Reference()
+    rng = np.random.default_rng(99)
+    for shape, p in [((31, 47), 1.6), ((64, 33), 6.4), ((20, 90), 12.8)]:
+        img = rng.random(shape, dtype=np.float32)
+        assert np.array_equal(bits(orc.gau_blur(img, p)), bits(ref.gau_blur(img, p)))
+    img = rng.random((53, 71), dtype=np.float32)
+    for z in (2.0, 1.0, 0.5, 0.25):
+        a, b = orc.first(img, z), ref.first(img, z)
+        assert not np.isnan(b).any()  # the reference never touched the row past the image
+        assert np.array_equal(bits(a), bits(b))
+
+
+def test_octave_count(orc):
+    # max(1, ceil(log2(max(w,h))) - 5), Sift.cpp:130-139
+    assert [orc.pyramid_octaves(*s) for s in [(640, 480), (1920, 1080), (3840, 2160), (8192, 8192), (32, 32)]] == \
+        [5, 6, 7, 8, 1]
+
+
+def test_extract_regression(orc):
+    z = np.load(os.path.join(G, "oracle_extract.npz"))
+    img = (z["img_a"].astype(np.float32).astype(np.float64) / 255.0).astype(np.float32)
+    f, h = orc.extract(img)
+    want = z["feat_a"]
+    assert len(f) == len(want) == 102
+    for k in ("size", "kai", "sigmaOCT", "x", "y", "sita"):
+        assert np.array_equal(f[k], want[k])
+    assert np.array_equal(bits(f["mm"]), bits(want["mm"]))
+    assert np.array_equal(f["descr"], want["descr"])
+    assert np.array_equal(bits(h), bits(z["hist_a"]))
+    # quirks the restatement must keep: descriptor = 512 * min(hist, 0.2) -> at most 102,
+    # sigmaOCT integer-truncated, orientation a multiple of 10
+    assert f["descr"].max() == 102
+    assert set(np.unique(f["sigmaOCT"])) <= {2.0, 3.0, 4.0, 6.0, 9.0, 12.0, 18.0}
+    assert (f["sita"] % 10 == 0).all()
+    # canonical order: octave (size descending), layer, row, column, bin
+    key = np.stack([-f["size"], f["kai"], f["y"], f["x"], f["sita"]], axis=1)
+    assert (np.lexsort(key.T[::-1]) == np.arange(len(f))).all()
+
+
+def test_fast_atan2f_regression(orc):
+    z = np.load(os.path.join(G, "oracle_extract.npz"))
+    got = np.array([orc.fast_atan2f(float(y), float(x)) for y, x in z["atan_in"]], np.float32)
+    assert np.array_equal(bits(got), bits(z["atan_out"]))
+    # against libm: the polynomial is good to ~0.01 degree
+    ref = np.degrees(np.arctan2(z["atan_in"][:, 0].astype(np.float64), z["atan_in"][:, 1].astype(np.float64))) % 360.0
+    err = np.abs(((got - ref + 180.0) % 360.0) - 180.0)
+    assert err.max() < 0.02
+
+
+def test_match_regression_and_forms(orc):
+    z = np.load(os.path.join(G, "oracle_extract.npz"))
+    q, r = z["feat_b"]["descr"], z["feat_a"]["descr"]
+    best, d1, d2 = orc.force_match(q.astype(np.float32), r.astype(np.float32), 0.5)
+    assert np.array_equal(best, z["force_best"]) and np.array_equal(d1, z["force_d1"])
+    bu, d1u, d2u = orc.match_u8(q, r, 0.5, 1)
+    # integer distances equal forceMatchFeat's float sums exactly (all below 2^24)
+    assert np.array_equal(d1u.astype(np.float32), d1) and np.array_equal(d2u.astype(np.float32), d2)
+    assert np.array_equal(bu, best)
+    b0, _, _ = orc.match_u8(q, r, 0.5, 0)
+    assert np.array_equal(b0, z["u8_best"])
+
+
+def test_match_edge_cases(orc):
+    q = np.zeros((3, 128), np.uint8)
+    r = np.zeros((1, 128), np.uint8)
+    r[0, 0] = 5
+    b0, d1, d2 = orc.match_u8(q, r, 0.5, 0)
+    assert (b0 == -1).all() and (d1 == 25).all() and (d2 == np.iinfo(np.int32).max).all()  # fewer than 2 refs
+    b1, _, _ = orc.match_u8(q, r, 0.5, 1)
+    assert (b1 == 0).all()  # forceMatchFeat's form divides by FLT_MAX and accepts
+    bq, _, _ = orc.match_u8(np.zeros((0, 128), np.uint8), r, 0.5, 0)
+    assert len(bq) == 0
+
+
+def test_kdtree_fixture_agrees_with_exact_nn(orc):
+    z = np.load(os.path.join(G, "kdtree_ref.npz"))
+    b, _, _ = orc.match_u8(z["q"], z["r"], float(z["th"]), 0)
+    agree = (b == z["kd_best"]).mean()
+    print("kd-tree (reference object code) vs exact NN agreement: %.4f" % agree)
+    assert agree > 0.95

@@ -1,0 +1,69 @@
+"""world_size-2 CPU (gloo) test of the sharded-match host logic: the result of
+query-sharding + reference all-gather must equal the single-process result."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, nq, nr, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sift_amd
+    from sift_amd.sharded import shard_bounds, sharded_match
+    from tests.oracle_lib import Oracle
+
+    orc = Oracle()
+    q, r = sift_amd.planted_descriptors(nq, nr, plant=0.2)
+    qb, qe = shard_bounds(nq, world, rank)
+    rb, re = shard_bounds(nr, world, rank)
+
+    def cpu_match(qt, rt, ratio, form):  # the checker stands in for the GPU kernel on CPU
+        b, d1, d2 = orc.match_u8(qt.numpy(), rt.numpy(), ratio, form)
+        return torch.from_numpy(b), torch.from_numpy(d1), torch.from_numpy(d2)
+
+    best, d1, d2 = sharded_match(cpu_match, torch.from_numpy(q[qb:qe]), torch.from_numpy(r[rb:re]), 0.5, 0)
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), best=best.numpy(), d1=d1.numpy(), d2=d2.numpy(), qb=qb, qe=qe)
+    dist.destroy_process_group()
+
+
+def _run(world, nq, nr, tmp_path, port):
+    mp.spawn(_worker, args=(world, port, nq, nr, str(tmp_path)), nprocs=world, join=True)
+    import sift_amd
+    from tests.oracle_lib import Oracle
+
+    q, r = sift_amd.planted_descriptors(nq, nr, plant=0.2)
+    bo, d1o, d2o = Oracle().match_u8(q, r, 0.5, 0)
+    got = np.full(nq, -2, np.int32)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"r{rank}.npz"))
+        got[int(z["qb"]): int(z["qe"])] = z["best"]
+        assert np.array_equal(z["d1"], d1o[int(z["qb"]): int(z["qe"])])
+    assert np.array_equal(got, bo)
+    assert (got >= 0).sum() > 0
+
+
+def test_sharded_match_even(tmp_path):
+    _run(2, 200, 300, tmp_path, 29611)
+
+
+def test_sharded_match_ragged(tmp_path):
+    _run(2, 201, 301, tmp_path, 29612)  # shards of different length: padded all-gather path
+
+
+def test_shard_bounds_cover():
+    from sift_amd.sharded import shard_bounds
+
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            segs = [shard_bounds(n, w, r) for r in range(w)]
+            assert segs[0][0] == 0 and segs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+            assert max(e - b for b, e in segs) - min(e - b for b, e in segs) <= 1
