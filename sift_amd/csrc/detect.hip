@@ -210,13 +210,24 @@ __device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
 // chunks, then lane b walks the chunk in order and adds the entries of bin b.
 constexpr int ORI_CH = 2048;
 
+// floor(th / 10) for th in [0, 360]: what (size_t)(sita / 10.0) yields in double
+// arithmetic (th / 10.0 is never within rounding distance of an integer unless th
+// is an exact multiple of 10), computed with exact float comparisons instead of a
+// double division.
+__device__ __forceinline__ int angle_bin(float th) {
+    int b = (int)(th * 0.1f);
+    if ((float)(10 * (b + 1)) <= th) b++;
+    if ((float)(10 * b) > th) b--;
+    return b;
+}
+
 __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ gau, size_t PX, int W,
                                                     const LayerConsts* __restrict__ lc,
                                                     const float* __restrict__ table, const Cand* __restrict__ cand,
                                                     const int* __restrict__ counters,
                                                     unsigned long long* __restrict__ cmask, float* __restrict__ cmm) {
-    __shared__ float s_val[ORI_CH];
-    __shared__ unsigned char s_bin[ORI_CH];
+    __shared__ __attribute__((aligned(16))) float s_val[ORI_CH];
+    __shared__ __attribute__((aligned(16))) unsigned char s_bin[ORI_CH];
     const int lane = threadIdx.x;
     const int ncand = counters[CNT_NCAND];
     for (int ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
@@ -228,13 +239,14 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
         const float* g1 = gau + (size_t)cd.layer * PX;  // dog[layer] = gau[layer] - gau[layer+1]
         const float* g2 = g1 + PX;
         const float* g = table + L.wts_off;
+        // window position of this lane's element, advanced by 64 elements per step
+        const int di = 64 / n, dj = 64 - di * n;
+        int jj = lane / n;
+        int ii = lane - jj * n;
         float sum = 0.f;
         for (int e0 = 0; e0 < total; e0 += ORI_CH) {
             const int cnt = min(ORI_CH, total - e0);
             for (int e = lane; e < cnt; e += 64) {
-                const int idx = e0 + e;
-                const int jj = idx / n;
-                const int ii = idx - jj * n;
                 const size_t p = (size_t)(cd.y - r + jj) * W + (cd.x - r + ii);
                 const float dx = (g1[p + 1] - g2[p + 1]) - (g1[p - 1] - g2[p - 1]);
                 const float dy = (g1[p + W] - g2[p + W]) - (g1[p - W] - g2[p - W]);
@@ -243,11 +255,26 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
                 mag = mag * g[ii];
                 mag = mag * g[jj];
                 s_val[e] = mag;
-                s_bin[e] = (unsigned char)(int)((double)th / 10.0);  // 36 == "one past the end": dropped
+                s_bin[e] = (unsigned char)angle_bin(th);  // 36 == "one past the end": dropped
+                ii += dj;
+                jj += di;
+                if (ii >= n) {
+                    ii -= n;
+                    jj++;
+                }
             }
             __syncthreads();
             if (lane < 36) {
-                for (int e = 0; e < cnt; e++) sum += (s_bin[e] == lane) ? s_val[e] : 0.f;
+                int e = 0;
+                for (; e + 4 <= cnt; e += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_val[e]);
+                    const unsigned b4 = *reinterpret_cast<const unsigned*>(&s_bin[e]);
+                    sum += ((b4 & 0xffu) == (unsigned)lane) ? v.x : 0.f;
+                    sum += (((b4 >> 8) & 0xffu) == (unsigned)lane) ? v.y : 0.f;
+                    sum += (((b4 >> 16) & 0xffu) == (unsigned)lane) ? v.z : 0.f;
+                    sum += ((b4 >> 24) == (unsigned)lane) ? v.w : 0.f;
+                }
+                for (; e < cnt; e++) sum += (s_bin[e] == lane) ? s_val[e] : 0.f;
             }
             __syncthreads();
         }
