@@ -4,6 +4,7 @@
 // point that does image or descriptor arithmetic runs the HIP kernels.
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -193,7 +194,13 @@ static int get_lane(sift_hip_ctx* ctx, int oi, OctWs** out) {
         if (ctx->lanes.empty()) {
             ws.stream = ctx->stream;
         } else {
-            if (hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking) != hipSuccess) return SIFT_HIP_ERR_HIP;
+            // the small octaves get the more urgent priority: they are short, latency-bound
+            // kernels that would otherwise queue behind octave 0's large grids
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = most urgent
+            const int prio = ctx->side_priority == 0 ? 0 : hi;
+            if (hipStreamCreateWithPriority(&ws.stream, hipStreamNonBlocking, prio) != hipSuccess)
+                return SIFT_HIP_ERR_HIP;
             ws.own_stream = true;
         }
         if (hipEventCreateWithFlags(&ws.ev_emit, hipEventDisableTiming) != hipSuccess ||
@@ -243,8 +250,6 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     const Plan& pl = ctx->plan;
     const int noct = (int)pl.oct.size();
     if ((rc = ensure(ctx, ctx->gcounters, G_SLOTS * sizeof(int)))) return rc;
-    if ((rc = ensure(ctx, ctx->feat, (size_t)std::max(1, feat_cap) * sizeof(sift_hip_feat)))) return rc;
-    if (want_hist && (rc = ensure(ctx, ctx->hist, (size_t)std::max(1, feat_cap) * 128 * sizeof(float)))) return rc;
     // all allocation first: ensure() may synchronise, which must not happen between launches
     for (int oi = 0; oi < noct; oi++) {
         OctWs* ws;
@@ -262,19 +267,31 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         if ((rc = ensure(ctx, ws->cand, (size_t)cand_cap * sizeof(Cand)))) return rc;
         if ((rc = ensure(ctx, ws->cand_mask, (size_t)cand_cap * sizeof(unsigned long long)))) return rc;
         if ((rc = ensure(ctx, ws->cand_mm, (size_t)cand_cap * 36 * sizeof(float)))) return rc;
+        if ((rc = ensure(ctx, ws->cand_off, (size_t)cand_cap * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ws->counters, CNT_SLOTS * sizeof(int)))) return rc;
+        if ((rc = ensure(ctx, ws->feat, (size_t)std::max(1, feat_cap) * sizeof(sift_hip_feat)))) return rc;
+        if (want_hist && (rc = ensure(ctx, ws->hist, (size_t)std::max(1, feat_cap) * 128 * sizeof(float)))) return rc;
     }
     if (!hip_ok(ctx, hipMemsetAsync(ctx->gcounters.p, 0, G_SLOTS * sizeof(int), ctx->stream), "reset counters"))
         return SIFT_HIP_ERR_HIP;
     hipEventRecord(ctx->ev_start, ctx->stream);
     const float thr = (float)((double)prm.dx_thr / 2.0);
-    const bool serial = ctx->profiling || ctx->force_serial;
+    const bool serial = ctx->profiling || ctx->force_serial || noct < 2;
+    // Streams: octave 0 (75 % of the pixels) on the context's stream, the smaller
+    // octaves one after another on a second, lower-priority stream that fills the
+    // gaps.  No octave waits for another; the context's stream is ordered after
+    // the second one at the end.
+    const int nside = 1;  // one extra stream
+    auto stream_of = [&](int oi) -> hipStream_t {
+        if (serial || oi == 0) return ctx->stream;
+        return ctx->lanes[std::min(oi, nside)].stream;
+    };
+    for (int s = 1; s <= nside && s < noct && !serial; s++) hipStreamWaitEvent(ctx->lanes[s].stream, ctx->ev_start, 0);
     for (int oi = 0; oi < noct; oi++) {
         OctWs& ws = ctx->lanes[oi];
-        const hipStream_t lane_stream = ws.stream;
-        if (serial) ws.stream = ctx->stream;
-        const hipStream_t st = ws.stream;
-        if (st != ctx->stream) hipStreamWaitEvent(st, ctx->ev_start, 0);
+        const hipStream_t own = ws.stream;
+        const hipStream_t st = stream_of(oi);
+        ws.stream = st;
         const OctavePlan& oc = pl.oct[oi];
         const size_t PX = (size_t)oc.W * oc.H;
         rc = run_octave_pyramid(ctx, ws, st, d_gray, oi);
@@ -282,10 +299,7 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
             const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
             launch_detect(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap);
             launch_orient(ctx, ws, PX, oc.W, d_lc, (const float*)ctx->table.p);
-            // features are appended in octave order: wait for the previous octave's emit
-            if (oi > 0 && ctx->lanes[oi - 1].stream != st) hipStreamWaitEvent(st, ctx->lanes[oi - 1].ev_emit, 0);
-            launch_emit(ctx, ws, oc.curr_size, d_lc, feat_cap);
-            hipEventRecord(ws.ev_emit, st);
+            launch_emit(ctx, ws, oi, oc.curr_size, d_lc, feat_cap);
             int max_window = 1;
             for (int li = 0; li < prm.intvls; li++) {
                 // descriptor radius of Sift.cpp:357 for this layer's integer-truncated sigma
@@ -294,18 +308,20 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
                 max_window = std::max(max_window, (2 * R + 1) * (2 * R + 1));
             }
             launch_descr(ctx, ws, PX, oc.W, oc.H, (const float*)ctx->table.p, feat_cap,
-                         want_hist ? (float*)ctx->hist.p : nullptr, max_window);
-            hipEventRecord(ws.ev_done, st);
+                         want_hist ? (float*)ws.hist.p : nullptr, max_window);
         }
-        ws.stream = lane_stream;
+        ws.stream = own;
         if (rc) return rc;
     }
-    if (!serial)
-        for (int oi = 1; oi < noct; oi++) hipStreamWaitEvent(ctx->stream, ctx->lanes[oi].ev_done, 0);
+    for (int s = 1; s <= nside && s < noct && !serial; s++) {
+        hipEventRecord(ctx->lanes[s].ev_done, ctx->lanes[s].stream);
+        hipStreamWaitEvent(ctx->stream, ctx->lanes[s].ev_done, 0);
+    }
     return check_async(ctx, "extract launch");
 }
 
-// Copies the counters back, then the features (and histograms) that fit.
+// Copies the counters back, then each octave's features (and histograms) to their
+// place in the caller's array: octave-major, as the reference appends them.
 static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow) {
     if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
                                     ctx->stream), "read counters"))
@@ -313,18 +329,26 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "extract")) return SIFT_HIP_ERR_HIP;
     *cand_overflow = ctx->h_counters[G_CAND_OVERFLOW];
     if (*cand_overflow) return SIFT_HIP_OK;
-    const int total = ctx->h_counters[G_FEAT_TOTAL];
-    *n = total;
-    const int m = std::min(total, cap);
-    if (m > 0) {
-        if (!hip_ok(ctx, hipMemcpyAsync(out, ctx->feat.p, (size_t)m * sizeof(sift_hip_feat), hipMemcpyDeviceToHost,
-                                        ctx->stream), "read features"))
-            return SIFT_HIP_ERR_HIP;
-        if (hist && !hip_ok(ctx, hipMemcpyAsync(hist, ctx->hist.p, (size_t)m * 128 * sizeof(float),
-                                                hipMemcpyDeviceToHost, ctx->stream), "read histograms"))
-            return SIFT_HIP_ERR_HIP;
-        if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "read features")) return SIFT_HIP_ERR_HIP;
+    const int noct = (int)ctx->plan.oct.size();
+    long long total = 0;
+    int copied = 0;
+    for (int oi = 0; oi < noct; oi++) {
+        const int cnt = ctx->h_counters[G_OCT_FEATS + oi];
+        const int m = std::max(0, std::min(cnt, cap - copied));  // the octave's buffer holds at most cap
+        if (m > 0) {
+            if (!hip_ok(ctx, hipMemcpyAsync(out + copied, ctx->lanes[oi].feat.p, (size_t)m * sizeof(sift_hip_feat),
+                                            hipMemcpyDeviceToHost, ctx->stream), "read features"))
+                return SIFT_HIP_ERR_HIP;
+            if (hist && !hip_ok(ctx, hipMemcpyAsync(hist + (size_t)copied * 128, ctx->lanes[oi].hist.p,
+                                                    (size_t)m * 128 * sizeof(float), hipMemcpyDeviceToHost,
+                                                    ctx->stream), "read histograms"))
+                return SIFT_HIP_ERR_HIP;
+            copied += m;
+        }
+        total += cnt;
     }
+    *n = (int)std::min<long long>(total, INT32_MAX);
+    if (copied > 0 && !hip_ok(ctx, hipStreamSynchronize(ctx->stream), "read features")) return SIFT_HIP_ERR_HIP;
     return total > cap ? SIFT_HIP_ERR_NOSPC : SIFT_HIP_OK;
 }
 
@@ -332,7 +356,8 @@ static int extract_dev_impl(sift_hip_ctx* ctx, const float* d_gray, int w, int h
                             sift_hip_feat* out, int cap, int* n, float* hist) {
     sift_hip_params prm;
     if (params) prm = *params; else sift_hip_default_params(&prm);
-    if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || !(prm.sigma0 > 0.f)) return SIFT_HIP_ERR_ARG;
+    if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || prm.octaves > 24 || !(prm.sigma0 > 0.f))
+        return SIFT_HIP_ERR_ARG;
     int cand_cap = std::max(ctx->cand_cap, std::max(cap, 1 << 16));
     for (int attempt = 0; attempt < 4; attempt++) {
         ctx->cand_cap = cand_cap;
@@ -372,6 +397,7 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     ctx->device = device;
     // SIFT_HIP_SERIAL=1: all octaves on one stream (clean per-kernel durations under a tracer)
     if (const char* e = std::getenv("SIFT_HIP_SERIAL")) ctx->force_serial = (e[0] == '1');
+    if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
@@ -391,14 +417,14 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     for (OctWs& ws : ctx->lanes) {
         if (ws.own_stream && ws.stream) hipStreamSynchronize(ws.stream);
         DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
-                        &ws.cand_mm, &ws.counters};
+                        &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist};
         for (DevBuf* b : wb)
             if (b->p) hipFree(b->p);
         if (ws.ev_emit) hipEventDestroy(ws.ev_emit);
         if (ws.ev_done) hipEventDestroy(ws.ev_done);
         if (ws.own_stream && ws.stream) hipStreamDestroy(ws.stream);
     }
-    DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->feat, &ctx->hist, &ctx->table, &ctx->layer_consts,
+    DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->table, &ctx->layer_consts,
                       &ctx->gcounters, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all};
     for (DevBuf* b : bufs)

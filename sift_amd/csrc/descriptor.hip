@@ -155,7 +155,7 @@ void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const f
     nthr = std::max(64, std::min(1024, nthr));
     const int blocks = 256 * std::max(2, 2048 / nthr);
     hipLaunchKernelGGL(descr_kernel, dim3(blocks), dim3(nthr), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H,
-                       d_cs, (sift_hip_feat*)ctx->feat.p, feat_cap, (const int*)ws.counters.p, d_hist);
+                       d_cs, (sift_hip_feat*)ws.feat.p, feat_cap, (const int*)ws.counters.p, d_hist);
 }
 
 }  // namespace sifthip

@@ -289,50 +289,58 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
 }
 
 // ---- FeatAppend order (Sift.cpp:229-249, :285-293) ------------------------------
-// One workgroup scans the per-candidate bin counts and writes the feature
-// records behind the features of earlier octaves.
-__global__ __launch_bounds__(1024) void emit_kernel(const Cand* __restrict__ cand,
-                                                    const unsigned long long* __restrict__ cmask,
-                                                    const float* __restrict__ cmm, const LayerConsts* __restrict__ lc,
-                                                    float curr_size, sift_hip_feat* __restrict__ feat, int feat_cap,
-                                                    int* __restrict__ counters, int* __restrict__ gcounters) {
+// One workgroup turns the per-candidate bin counts into output offsets within the
+// octave's feature buffer; a grid then writes the feature records.
+__global__ __launch_bounds__(1024) void emit_scan_kernel(const unsigned long long* __restrict__ cmask,
+                                                         int* __restrict__ cand_off, int* __restrict__ counters,
+                                                         int* __restrict__ gcounters, int octave) {
     __shared__ int s_warp[40];
     const int ncand = counters[CNT_NCAND];
-    const int begin = gcounters[G_FEAT_TOTAL];
+    const int begin = 0;  // every octave fills its own feature buffer
     int running = begin;
     for (int b = 0; b < ncand; b += 1024) {
         const int i = b + threadIdx.x;
-        unsigned long long m = (i < ncand) ? cmask[i] : 0ull;
-        const int v = __popcll(m);
+        const int v = (i < ncand) ? __popcll(cmask[i]) : 0;
         int total;
         const int ex = block_excl_scan_1024(v, s_warp, total);
-        if (v) {
-            const Cand cd = cand[i];
-            const LayerConsts L = lc[cd.layer - 1];
-            int pos = running + ex;
-            while (m) {
-                const int bin = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (pos < feat_cap) {
-                    sift_hip_feat* f = feat + pos;
-                    f->size = curr_size;
-                    f->kai = cd.layer;
-                    f->sigmaOCT = L.sigma_oct;
-                    f->x = cd.x;
-                    f->y = cd.y;
-                    f->mm = cmm[(size_t)i * 36 + bin];
-                    f->sita = bin * 10;
-                }
-                pos++;
-            }
-        }
+        if (i < ncand) cand_off[i] = running + ex;
         running += total;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         counters[CNT_OCT_BEGIN] = begin;
         counters[CNT_OCT_END] = running;
-        gcounters[G_FEAT_TOTAL] = running;
+        gcounters[G_OCT_FEATS + octave] = running;
+    }
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(const Cand* __restrict__ cand,
+                                                   const unsigned long long* __restrict__ cmask,
+                                                   const float* __restrict__ cmm, const int* __restrict__ cand_off,
+                                                   const LayerConsts* __restrict__ lc, float curr_size,
+                                                   sift_hip_feat* __restrict__ feat, int feat_cap,
+                                                   const int* __restrict__ counters) {
+    const int ncand = counters[CNT_NCAND];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
+        unsigned long long m = cmask[i];
+        const Cand cd = cand[i];
+        const LayerConsts L = lc[cd.layer - 1];
+        int pos = cand_off[i];
+        while (m) {
+            const int bin = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < feat_cap) {
+                sift_hip_feat* f = feat + pos;
+                f->size = curr_size;
+                f->kai = cd.layer;
+                f->sigmaOCT = L.sigma_oct;
+                f->x = cd.x;
+                f->y = cd.y;
+                f->mm = cmm[(size_t)i * 36 + bin];
+                f->sita = bin * 10;
+            }
+            pos++;
+        }
     }
 }
 
@@ -365,11 +373,15 @@ void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerCo
                        (float*)ws.cand_mm.p);
 }
 
-void launch_emit(sift_hip_ctx* ctx, OctWs& ws, float curr_size, const LayerConsts* d_lc, int feat_cap) {
+void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap) {
     ProfScope ps(ctx, SIFT_HIP_K_EMIT, ws.stream);
-    hipLaunchKernelGGL(emit_kernel, dim3(1), dim3(1024), 0, ws.stream, (const Cand*)ws.cand.p,
-                       (const unsigned long long*)ws.cand_mask.p, (const float*)ws.cand_mm.p, d_lc, curr_size,
-                       (sift_hip_feat*)ctx->feat.p, feat_cap, (int*)ws.counters.p, (int*)ctx->gcounters.p);
+    hipLaunchKernelGGL(emit_scan_kernel, dim3(1), dim3(1024), 0, ws.stream,
+                       (const unsigned long long*)ws.cand_mask.p, (int*)ws.cand_off.p, (int*)ws.counters.p,
+                       (int*)ctx->gcounters.p, octave);
+    hipLaunchKernelGGL(emit_kernel, dim3(128), dim3(256), 0, ws.stream, (const Cand*)ws.cand.p,
+                       (const unsigned long long*)ws.cand_mask.p, (const float*)ws.cand_mm.p,
+                       (const int*)ws.cand_off.p, d_lc, curr_size, (sift_hip_feat*)ws.feat.p, feat_cap,
+                       (const int*)ws.counters.p);
 }
 
 }  // namespace sifthip

@@ -25,9 +25,9 @@ enum Counter {
 };
 // Slots of the per-context (all octaves) counter block.
 enum GlobalCounter {
-    G_FEAT_TOTAL = 0,     // features emitted so far, octave by octave
-    G_CAND_OVERFLOW = 1,  // largest candidate count that did not fit, 0 if all fit
-    G_SLOTS = 8
+    G_CAND_OVERFLOW = 0,  // largest candidate count that did not fit, 0 if all fit
+    G_OCT_FEATS = 1,      // G_OCT_FEATS + o: features found in octave o (may exceed the capacity)
+    G_SLOTS = 32
 };
 
 struct DevBuf {
@@ -35,14 +35,15 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-// Octaves are independent until their features are appended (Sift.cpp:145-149:
-// every octave restarts from the original image), so each one gets its own HIP
-// stream and workspace; only emit/describe are chained in octave order.
+// Octaves are independent (Sift.cpp:145-149: every octave restarts from the
+// original image), so each one has its own workspace and feature buffer and runs
+// on one of a few HIP streams; the octave-major output order of the reference is
+// restored by the order of the device-to-host copies.
 struct OctWs {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_emit = nullptr, ev_done = nullptr;
-    DevBuf base, tmp, gau_all, masks, row_cnt, row_off, cand, cand_mask, cand_mm, counters;
+    DevBuf base, tmp, gau_all, masks, row_cnt, row_off, cand, cand_mask, cand_mm, cand_off, counters, feat, hist;
 };
 
 struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-183)
@@ -75,7 +76,7 @@ struct sift_hip_ctx {
 
     sifthip::Plan plan;
     // device workspace (grown on demand, never shrunk)
-    sifthip::DevBuf in_img, in_rgb, tmp, feat, hist, table, layer_consts, gcounters, qi8, ri8, qnorm, rconst, best,
+    sifthip::DevBuf in_img, in_rgb, tmp, table, layer_consts, gcounters, qi8, ri8, qnorm, rconst, best,
         d1, d2, io_a, io_b, frame2, dog_all;
     std::vector<sifthip::OctWs> lanes;  // lanes[0] runs on `stream`
     hipEvent_t ev_start = nullptr;
@@ -87,6 +88,7 @@ struct sift_hip_ctx {
     // profiling
     bool profiling = false;
     bool force_serial = false;
+    int side_priority = 1;          // 1: the small-octave stream is created with the urgent priority
     struct Ev { int cls; hipEvent_t a, b; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> free_events;
@@ -132,7 +134,7 @@ struct LayerConsts {  // per DoG layer 1..intvls of one octave
 void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
                    float thr, int cand_cap);
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table);
-void launch_emit(sift_hip_ctx* ctx, OctWs& ws, float curr_size, const LayerConsts* d_lc, int feat_cap);
+void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap);
 // descriptor.hip; max_window: sample count (2R+1)^2 of the octave's largest descriptor window
 void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const float* d_cs, int feat_cap,
                   float* d_hist, int max_window);

@@ -74,7 +74,8 @@ void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, in
 }
 
 // ---- separable blur ----------------------------------------------------------------
-constexpr int P = 8;  // outputs per thread along the filter direction
+// P = outputs per thread along the filter direction: 8 for large octaves (one LDS
+// read per 8 MACs), 2 for small ones, which otherwise cannot fill 1024 SIMDs.
 
 template <typename ACC>
 __device__ __forceinline__ void mac(ACC& acc, float a, float g);
@@ -88,11 +89,13 @@ __device__ __forceinline__ void mac<float>(float& acc, float a, float g) {
     acc = fmaf(a, g, acc);
 }
 
-// LDS index with one pad word per 8 so that lanes 8 floats apart hit distinct banks.
-__device__ __forceinline__ int padx(int i) { return i + (i >> 3); }
+// LDS index with one pad word per P so that lanes P floats apart hit distinct banks
+// (lane stride P+1 words, odd).
+template <int P>
+__device__ __forceinline__ int padx(int i) { return i + i / P; }
 
 // Row pass: one wave per 512-pixel run of one row.  LDS holds the run plus halo.
-template <typename ACC>
+template <typename ACC, int P>
 __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
                                                       int H, const float* __restrict__ taps, int K) {
     extern __shared__ float s[];
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
     for (int i = lane; i < n_in; i += 64) {
         int gx = x0 + i - r;
         gx = max(0, min(gx, W - 1));
-        s[padx(i)] = row[gx];
+        s[padx<P>(i)] = row[gx];
     }
     __syncthreads();
     const int base = lane * P;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
 #pragma unroll
     for (int p = 0; p < P; p++) {
         acc[p] = 0;
-        win[p] = s[padx(base + p)];
+        win[p] = s[padx<P>(base + p)];
     }
     int k = 0;
     for (; k + P <= K; k += P) {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
             const float g = taps[k + u];
 #pragma unroll
             for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = s[padx(base + k + u + P)];
+            win[u] = s[padx<P>(base + k + u + P)];
         }
     }
 #pragma unroll
@@ -133,16 +136,20 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
             const float g = taps[k + u];
 #pragma unroll
             for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = s[padx(base + k + u + P)];
+            win[u] = s[padx<P>(base + k + u + P)];
         }
     }
     float* o = out + (size_t)y * W + x0 + base;
-    if ((W & 3) == 0 && x0 + base + P <= W) {
-        float4 a = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
-        float4 b = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
-        reinterpret_cast<float4*>(o)[0] = a;
-        reinterpret_cast<float4*>(o)[1] = b;
-    } else {
+    if constexpr (P == 8) {
+        if ((W & 3) == 0 && x0 + base + P <= W) {
+            float4 a = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+            float4 b = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
+            reinterpret_cast<float4*>(o)[0] = a;
+            reinterpret_cast<float4*>(o)[1] = b;
+            return;
+        }
+    }
+    {
 #pragma unroll
         for (int p = 0; p < P; p++)
             if (x0 + base + p < W) o[p] = (float)acc[p];
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
 
 // Column pass: a 256-thread workgroup owns 64 columns x TH rows; LDS holds the
 // TH + K - 1 input rows.  Each wave takes P-row chunks.
-template <typename ACC>
+template <typename ACC, int P>
 __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
                                                        int H, const float* __restrict__ taps, int K, int TH) {
     extern __shared__ float s[];
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__
 
 // Column pass for kernels too long for an LDS tile: the window slides over rows
 // read straight from global memory (L1/L2 serve the overlap between row chunks).
-template <typename ACC>
+template <typename ACC, int P>
 __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               int W, int H, const float* __restrict__ taps, int K) {
     const int lane = threadIdx.x & 63;
@@ -261,33 +268,42 @@ __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __res
 
 constexpr int kMaxColLds = 64 * 1024;  // largest LDS tile the column pass may request
 
-template <typename ACC>
-static void launch_blur_t(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
-                          const float* d_taps, int K) {
+template <typename ACC, int P>
+static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
+                           const float* d_taps, int K) {
     {
         ProfScope ps(ctx, SIFT_HIP_K_BLUR_ROW, st);
         const int n_in = 64 * P + K - 1 + P;
-        const size_t lds = (size_t)(n_in + (n_in >> 3) + 1) * sizeof(float);
+        const size_t lds = (size_t)(n_in + n_in / P + 1) * sizeof(float);
         dim3 grid((W + 64 * P - 1) / (64 * P), H);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC>), grid, dim3(64), lds, st, src, tmp, W, H,
-                           d_taps, K);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC, P>), grid, dim3(64), lds, st, src, tmp, W, H, d_taps,
+                           K);
     }
     {
         ProfScope ps(ctx, SIFT_HIP_K_BLUR_COL, st);
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
-        int TH = 128;
-        while (TH > 32 && (size_t)(TH + K - 1 + P) * 256 > 48 * 1024) TH >>= 1;
+        int TH = 16 * P;
+        while (TH > 4 * P && (size_t)(TH + K - 1 + P) * 256 > 48 * 1024) TH >>= 1;
         const size_t lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
         if (lds <= (size_t)kMaxColLds) {
             dim3 grid((W + 63) / 64, (H + TH - 1) / TH);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC>), grid, dim3(256), lds, st, tmp, dst, W, H,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC, P>), grid, dim3(256), lds, st, tmp, dst, W, H,
                                d_taps, K, TH);
         } else {
             dim3 grid((W + 63) / 64, (H + 4 * P - 1) / (4 * P));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_global_kernel<ACC>), grid, dim3(256), 0, st, tmp, dst,
-                               W, H, d_taps, K);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_global_kernel<ACC, P>), grid, dim3(256), 0, st, tmp, dst, W, H,
+                               d_taps, K);
         }
     }
+}
+
+template <typename ACC>
+static void launch_blur_t(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
+                          const float* d_taps, int K) {
+    if ((size_t)W * H < (size_t)3 << 20)
+        launch_blur_tp<ACC, 2>(ctx, st, src, tmp, dst, W, H, d_taps, K);
+    else
+        launch_blur_tp<ACC, 8>(ctx, st, src, tmp, dst, W, H, d_taps, K);
 }
 
 void launch_blur(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
