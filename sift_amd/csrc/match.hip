@@ -9,10 +9,14 @@
 // Arithmetic: descriptors are bytes; x - 128 fits int8 and leaves distances
 // unchanged, so |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b' with the dot product on the
 // int8 MFMA and everything else in int32: exact.  The search maximises
-// s = 2 a'.b' - |b'|^2 per query.  Per MFMA output element the epilogue is three
-// VALU instructions: key = (dot << 9) + c_ref (c_ref = -|b'|^2 * 256 + 255 - slot,
-// slot = reference index mod 256), m2 = med3(m1, m2, key), m1 = max(m1, key); the
-// low byte makes the lowest index win ties and is decoded every 256 references.
+// s = 2 a'.b' - |b'|^2 per query through keys key = (dot << 9) + c_ref with
+// c_ref = -|b'|^2 * 256 + 255 - slot (slot = reference index mod 256): the low
+// byte makes the lowest index win ties and is decoded every 256 references.  The
+// running top-2 update is m2 = med3(m1, m2, key), m1 = max(m1, key), but it is
+// reached only by tiles that pass a max-over-tile threshold test (see match_kernel).
+#include <algorithm>
+#include <cstdlib>
+
 #include "internal.h"
 
 namespace sifthip {
@@ -21,14 +25,17 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kNone = (int)0x80000000;  // "no key yet"
-constexpr int RT = 128;                 // references per LDS stage
-constexpr int NB = 2;                   // 32-query blocks per wave
-constexpr int QPW = 32 * NB;            // queries per wave
-constexpr int QPB = 4 * QPW;            // queries per workgroup
+#ifndef MATCH_RT
+#define MATCH_RT 256
+#endif
+constexpr int RT = MATCH_RT;            // references per LDS stage
 constexpr int GROUP = 256;              // references per key-decoding group
+// NB = 32-query blocks per wave (template parameter): 4 when there are enough
+// queries to fill the chip with 512-query workgroups, else 2.
 
 // bytes -> int8 (x - 128), row norms; mode 0: norm[i] = |row|^2 (queries),
-// mode 1: norm[i] = c_ref (references).  Rows >= n are zero padding.
+// mode 1: norm[i] = c_ref >> 9 and norm[n_pad + i] = c_ref & 511 (references).
+// Rows >= n are zero padding.
 __global__ __launch_bounds__(256) void match_prep_kernel(const uint8_t* __restrict__ src, int n, int n_pad,
                                                          int8_t* __restrict__ dst, int* __restrict__ norm, int mode) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -54,8 +61,13 @@ __global__ __launch_bounds__(256) void match_prep_kernel(const uint8_t* __restri
     part += __shfl_xor(part, 2);
     part += __shfl_xor(part, 4);
     if (ch == 0) {
-        if (mode == 0) norm[row] = part;
-        else norm[row] = (row < n) ? (-part * 256 + 255 - (row & (GROUP - 1))) : kNone;
+        if (mode == 0) {
+            norm[row] = part;
+        } else {
+            const int c = (row < n) ? (-part * 256 + 255 - (row & (GROUP - 1))) : kNone;
+            norm[row] = c >> 9;
+            norm[n_pad + row] = c & 511;
+        }
     }
 }
 
@@ -63,14 +75,19 @@ __global__ __launch_bounds__(256) void match_prep_kernel(const uint8_t* __restri
 __device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 
 struct Top2 {
-    int b1, i1, b2;
+    int b1, i1, b2;  // best s, its reference index, second-best s (kNone = none)
 };
 
+// Pseudo-key that stands for "the global second best" inside a group: any real
+// key of this group that could change the global top-2 is larger than it.
+__device__ __forceinline__ int floor_key(const Top2& t) { return (t.b2 == kNone) ? kNone : ((t.b2 << 8) | 255); }
+
 __device__ __forceinline__ void fold_group(Top2& t, int& m1, int& m2, int gbase) {
-    if (m1 != kNone) {
+    const int F = floor_key(t);
+    if (m1 > F) {
         const int s1 = m1 >> 8;
         const int idx = gbase + 255 - (m1 & 255);
-        const int s2 = (m2 == kNone) ? kNone : (m2 >> 8);
+        const int s2 = (m2 > F) ? (m2 >> 8) : kNone;
         if (s1 > t.b1) {
             t.b2 = max(t.b1, s2);
             t.b1 = s1;
@@ -79,21 +96,28 @@ __device__ __forceinline__ void fold_group(Top2& t, int& m1, int& m2, int gbase)
             t.b2 = max(t.b2, s1);
         }
     }
-    m1 = kNone;
-    m2 = kNone;
+    m1 = m2 = floor_key(t);
 }
 
+// The accumulators start from ci = c_ref >> 9, so an MFMA result is
+// dot + ci = key >> 9.  A tile can only change a query's top-2 if one of its 16
+// values reaches thr = m2 >> 9; that test (8 v_max3 per tile) replaces the
+// 3-instructions-per-value update, which runs only for the rare tiles that pass.
+template <int NB>
 __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q, const int* __restrict__ qnorm,
                                                     int nq, const int8_t* __restrict__ r,
                                                     const int* __restrict__ rc, int nr, int nr_pad, float ratio,
                                                     int ratio_form, int* __restrict__ best, int* __restrict__ d1o,
                                                     int* __restrict__ d2o) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_ref[RT * 128];
-    __shared__ __attribute__((aligned(16))) int s_c[RT];
+    // two LDS stages of RT references: [bytes RT*128][ci RT][lo RT]
+    constexpr int STAGE = RT * 128 + RT * 8;
+    __shared__ __attribute__((aligned(1024))) unsigned char s_all[2 * STAGE];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jq = lane & 31, h = lane >> 5;
-    const int qbase = blockIdx.x * QPB + wave * QPW;
+    constexpr int QPW = 32 * NB;  // queries per wave
+    const int qbase = blockIdx.x * (4 * QPW) + wave * QPW;
 
     // this wave's queries stay in registers as MFMA B operands for the whole sweep
     v4i bq[NB][4];
@@ -104,54 +128,159 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
         for (int s = 0; s < 4; s++) bq[b][s] = *reinterpret_cast<const v4i*>(row + 32 * s + 16 * h);
     }
     Top2 top[NB];
-    int m1[NB], m2[NB];
+    int m1[NB], m2[NB], thr[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         top[b] = Top2{kNone, -1, kNone};
         m1[b] = kNone;
         m2[b] = kNone;
+        thr[b] = kNone >> 9;
     }
 
-    for (int st = 0; st < nr_pad; st += RT) {
-        // stage RT references: 16-byte chunks, XOR-swizzled so that the operand
-        // reads below (32 rows x one chunk column) are bank-conflict free
+    // Stage loads go global -> LDS directly (no registers, no ds_write).  One wave
+    // instruction fills 1 KB = 8 reference rows; lane i lands at row i>>3, 16-byte
+    // slot i&7, so the XOR swizzle that makes the operand reads conflict-free is
+    // applied to the SOURCE chunk each lane fetches.
+    constexpr int NPIECE = RT / 8 / 4;  // 1-KB pieces per wave and stage
+    auto fetch = [&](int st, int buf) {
+        unsigned char* base = s_all + buf * STAGE;
 #pragma unroll
-        for (int u = 0; u < (RT * 8) / 256; u++) {
-            const int t = tid + 256 * u;
-            const int row = t >> 3, ch = t & 7;
-            const v4i v = *reinterpret_cast<const v4i*>(r + (size_t)(st + row) * 128 + ch * 16);
-            *reinterpret_cast<v4i*>(s_ref + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = v;
+        for (int u = 0; u < NPIECE; u++) {
+            const int piece = wave * NPIECE + u;
+            const int row = piece * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(r + (size_t)(st + row) * 128 + ch * 16),
+                (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, 0, 0);
         }
-        if (tid < RT) s_c[tid] = rc[st + tid];
-        __syncthreads();
+        // the per-reference constants (ci then lo, RT ints each) the same way, 64 ints
+        // per wave instruction, so that the loop holds no register-destination load
+        // whose wait would also drain the DMA
+        constexpr int NCI = 2 * RT / 64;  // wave instructions for ci + lo
 #pragma unroll
-        for (int tile = 0; tile < RT / 32; tile++) {
+        for (int u = 0; u < (NCI + 3) / 4; u++) {
+            const int k = wave + 4 * u;  // wave-uniform
+            if (k < NCI) {
+                const int* src = (k < NCI / 2) ? (rc + st + k * 64) : (rc + nr_pad + st + (k - NCI / 2) * 64);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane),
+                                                 (__attribute__((address_space(3))) void*)(base + RT * 128 + k * 256),
+                                                 4, 0, 0);
+            }
+        }
+    };
+    fetch(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int st = 0; st < nr_pad; st += RT, buf ^= 1) {
+        const unsigned char* s_ref = s_all + buf * STAGE;
+        const int* s_ci = reinterpret_cast<const int*>(s_ref + RT * 128);
+        const int* s_lo = s_ci + RT;
+        if (st + RT < nr_pad) fetch(st + RT, buf ^ 1);
+
+        // Fast pass over the stage's tiles, branch-free so that LDS reads, MFMA
+        // chains and the threshold tests of neighbouring tiles overlap: it only
+        // records WHICH tiles could change some query's top-2.  thr is not raised
+        // inside the pass (a stale, lower threshold only flags more tiles).
+        unsigned hotmask = 0;
+        // operands of tile t+1 are read from LDS before the MFMAs of tile t are issued
+        auto load_tile = [&](int tile, v4i (&a)[4], v16i& ci) {
             const int row = tile * 32 + jq;
-            v4i a[4];
 #pragma unroll
             for (int s = 0; s < 4; s++)
                 a[s] = *reinterpret_cast<const v4i*>(s_ref + row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4));
-            v4i cv[4];
+            // accumulator register e holds reference row (e&3) + 8*(e>>2) + 4*h of the tile
 #pragma unroll
-            for (int g = 0; g < 4; g++) cv[g] = *reinterpret_cast<const v4i*>(&s_c[tile * 32 + 8 * g + 4 * h]);
+            for (int g = 0; g < 4; g++) {
+                const v4i t = *reinterpret_cast<const v4i*>(&s_ci[tile * 32 + 8 * g + 4 * h]);
+                ci[4 * g + 0] = t[0];
+                ci[4 * g + 1] = t[1];
+                ci[4 * g + 2] = t[2];
+                ci[4 * g + 3] = t[3];
+            }
+        };
+        v4i a_cur[4], a_nxt[4];
+        v16i ci_cur, ci_nxt;
+        load_tile(0, a_cur, ci_cur);
 #pragma unroll
-            for (int b = 0; b < NB; b++) {
-                v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int tile = 0; tile < RT / 32; tile++) {
+            if (tile + 1 < RT / 32) load_tile(tile + 1, a_nxt, ci_nxt);
+            // the threshold test of chain b is issued after the MFMAs of chain b+1, so
+            // the wave never idles on a chain's result while the matrix pipe is free
+            bool hot = false;
+            auto chain = [&](int b) {
+                v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[0], bq[b][0], ci_cur, 0, 0, 0);
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[b][s], acc, 0, 0, 0);
+                for (int s = 1; s < 4; s++)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[s], bq[b][s], acc, 0, 0, 0);
+                return acc;
+            };
+            auto test = [&](const v16i& acc, int b) {
+                int mx = max(max(acc[0], acc[1]), acc[2]);
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    // accumulator register e holds reference row (e&3) + 8*(e>>2) + 4*h of the tile
-                    const int key = (acc[e] << 9) + cv[e >> 2][e & 3];
-                    m2[b] = med3i(m1[b], m2[b], key);
-                    m1[b] = max(m1[b], key);
+                for (int e = 3; e + 1 < 16; e += 2) mx = max(max(mx, acc[e]), acc[e + 1]);
+                mx = max(mx, acc[15]);
+                hot |= (mx >= thr[b]);
+            };
+            v16i acc_prev = chain(0);
+#pragma unroll
+            for (int b = 1; b < NB; b++) {
+                const v16i acc_now = chain(b);
+                __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs ahead of the previous chain's test
+                test(acc_prev, b - 1);
+                acc_prev = acc_now;
+            }
+            test(acc_prev, NB - 1);
+            hotmask |= (__ballot(hot) != 0ull) ? (1u << tile) : 0u;
+            if (tile + 1 < RT / 32) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) a_cur[s] = a_nxt[s];
+                ci_cur = ci_nxt;
+            }
+        }
+        // Slow pass (rare once a few thousand references are in): redo the flagged
+        // tiles and run the exact top-2 update on every value.
+        if (hotmask) {
+            for (int tile = 0; tile < RT / 32; tile++) {
+                if (!((hotmask >> tile) & 1u)) continue;
+                const int row = tile * 32 + jq;
+                v4i a[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    a[s] = *reinterpret_cast<const v4i*>(s_ref + row * 128 + (((2 * s + h) ^ ((row >> 1) & 7)) << 4));
+                v16i ci;
+                v4i lo[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const v4i t = *reinterpret_cast<const v4i*>(&s_ci[tile * 32 + 8 * g + 4 * h]);
+                    lo[g] = *reinterpret_cast<const v4i*>(&s_lo[tile * 32 + 8 * g + 4 * h]);
+                    ci[4 * g + 0] = t[0];
+                    ci[4 * g + 1] = t[1];
+                    ci[4 * g + 2] = t[2];
+                    ci[4 * g + 3] = t[3];
+                }
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[b][0], ci, 0, 0, 0);
+#pragma unroll
+                    for (int s = 1; s < 4; s++)
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[b][s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int key = (acc[e] << 9) + lo[e >> 2][e & 3];
+                        m2[b] = med3i(m1[b], m2[b], key);
+                        m1[b] = max(m1[b], key);
+                    }
+                    thr[b] = m2[b] >> 9;
                 }
             }
         }
         if (((st + RT) & (GROUP - 1)) == 0) {
             const int gbase = (st + RT) - GROUP;
 #pragma unroll
-            for (int b = 0; b < NB; b++) fold_group(top[b], m1[b], m2[b], gbase);
+            for (int b = 0; b < NB; b++) {
+                fold_group(top[b], m1[b], m2[b], gbase);
+                thr[b] = m2[b] >> 9;
+            }
         }
         __syncthreads();
     }
@@ -194,21 +323,30 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
 
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio, int ratio_form,
               int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
-    const int nq_pad = (nq + QPB - 1) / QPB * QPB;
+    bool big = nq >= 512 * 512;  // >= 2 workgroups of 512 queries per CU
+    if (const char* e = std::getenv("SIFT_MATCH_NB")) big = (e[0] == '4');
+    const int qpb = big ? 512 : 256;
+    const int nq_pad = (nq + qpb - 1) / qpb * qpb;
     const int nr_pad = (nr + RT - 1) / RT * RT;
     int rc;
     if ((rc = ensure(ctx, ctx->qi8, (size_t)nq_pad * 128))) return rc;
-    if ((rc = ensure(ctx, ctx->ri8, (size_t)nr_pad * 128))) return rc;
+    if ((rc = ensure(ctx, ctx->ri8, (size_t)std::max(nr_pad, RT) * 128))) return rc;
     if ((rc = ensure(ctx, ctx->qnorm, (size_t)nq_pad * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->rconst, (size_t)nr_pad * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->rconst, (size_t)std::max(nr_pad, RT) * 8))) return rc;
     ProfScope ps(ctx, SIFT_HIP_K_MATCH, ctx->stream);
     hipLaunchKernelGGL(match_prep_kernel, dim3((nq_pad * 8 + 255) / 256), dim3(256), 0, ctx->stream, d_q, nq, nq_pad,
                        (int8_t*)ctx->qi8.p, (int*)ctx->qnorm.p, 0);
-    hipLaunchKernelGGL(match_prep_kernel, dim3((nr_pad * 8 + 255) / 256), dim3(256), 0, ctx->stream, d_r, nr, nr_pad,
-                       (int8_t*)ctx->ri8.p, (int*)ctx->rconst.p, 1);
-    hipLaunchKernelGGL(match_kernel, dim3(nq_pad / QPB), dim3(256), 0, ctx->stream, (const int8_t*)ctx->qi8.p,
-                       (const int*)ctx->qnorm.p, nq, (const int8_t*)ctx->ri8.p, (const int*)ctx->rconst.p, nr, nr_pad,
-                       ratio, ratio_form, d_best, d_d1, d_d2);
+    if (nr_pad > 0)
+        hipLaunchKernelGGL(match_prep_kernel, dim3((nr_pad * 8 + 255) / 256), dim3(256), 0, ctx->stream, d_r, nr,
+                           nr_pad, (int8_t*)ctx->ri8.p, (int*)ctx->rconst.p, 1);
+    if (big)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(match_kernel<4>), dim3(nq_pad / qpb), dim3(256), 0, ctx->stream,
+                           (const int8_t*)ctx->qi8.p, (const int*)ctx->qnorm.p, nq, (const int8_t*)ctx->ri8.p,
+                           (const int*)ctx->rconst.p, nr, nr_pad, ratio, ratio_form, d_best, d_d1, d_d2);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(match_kernel<2>), dim3(nq_pad / qpb), dim3(256), 0, ctx->stream,
+                           (const int8_t*)ctx->qi8.p, (const int*)ctx->qnorm.p, nq, (const int8_t*)ctx->ri8.p,
+                           (const int*)ctx->rconst.p, nr, nr_pad, ratio, ratio_form, d_best, d_d1, d_d2);
     return SIFT_HIP_OK;
 }
 

@@ -26,6 +26,7 @@ ctx = sift_amd.SiftHip(0)
 frame = sift_amd.blob_image(a.width, a.height, seed=1)
 d = torch.from_numpy(frame).cuda()
 out = np.zeros(1 << 16, sift_amd.FEAT_DTYPE)
+n = 0
 for _ in range(a.steps):
     n = ctx.extract_dev(d, a.width, a.height, SiftParams(octaves=a.octaves, blur_mode=a.blur_mode), out)
 print("features", n)
