@@ -101,7 +101,8 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     frames_per_s = world * args.steps / dt
 
-    # ---- roofline of the pyramid kernels: HIP events on the library's stream ------------
+    # ---- roofline: HIP events recorded by the library on the stream it launches on ----------
+    # (profiling mode runs the octaves on one stream, so durations are not inflated by overlap)
     roofline = None
     if rank == 0:
         ctx.profile(True)
@@ -113,26 +114,67 @@ def main():
         ctx.profile(False)
         px = pyramid_pixels(W, H, args.octaves)
         levels = prm.intvls + 3
-        # algorithmic bytes per octave pixel: each Gaussian level read + written
-        # once (8 B), each DoG layer written once (4 B): 6*8 + 5*4 = 68 B
-        alg_pyr = sum(px) * (levels * 8 + (levels - 1) * 4)
-        t_pyr_ms = (prof["blur_row"][0] + prof["blur_col"][0]) / nprof
-        launches = (prof["blur_row"][1] + prof["blur_col"][1]) // nprof
-        achieved = alg_pyr / (t_pyr_ms * 1e-3) / 1e9
+        # algorithmic bytes of the pyramid+DoG stage: 68 B per octave pixel = 6 levels x (4 B read
+        # + 4 B write) + 5 DoG layers x 4 B; the stage is 2 launches per level (row pass, column
+        # pass), so one launch over PX pixels carries 68/12 B per pixel.
+        stage_bytes_per_px = levels * 8 + (levels - 1) * 4
+        per_launch_bytes_per_px = stage_bytes_per_px / (2.0 * levels)
+        big = [p for p in px if p >= (3 << 20)]          # octaves handled by the 8-outputs-per-thread kernels
+        dom = max(("blur_col", "blur_row"), key=lambda k: prof[k][0])
+        n_dom = prof[dom][1] // nprof
+        avg_ms = prof[dom][0] / max(prof[dom][1], 1)
+        alg_launch = per_launch_bytes_per_px * (sum(big) * levels / max(n_dom, 1))
+        achieved = alg_launch / (avg_ms * 1e-3) / 1e9
+        blur_keys = ("blur_row", "blur_col", "blur_row_small", "blur_col_small")
+        t_stage = sum(prof[k][0] for k in blur_keys) / nprof
+        alg_stage = sum(px) * stage_bytes_per_px
+        traffic = None
+        traffic_note = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        kname = {"blur_col": "blur_col_kernel<double, 8>", "blur_row": "blur_row_kernel<double, 8>"}[dom] \
+            if args.blur_mode == 0 else None
+        if kname and os.path.exists(tpath) and (W, H, args.octaves) == (3840, 2160, 4):
+            tj = json.load(open(tpath))
+            kk = tj["kernels"].get(kname)
+            if kk:
+                traffic = round((kk["read"] + kk["write"]) / kk["launches_per_frame"])
+                traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this workload, " \
+                               "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, per launch; profiles/r01_traffic.json"
+        # VALU floor of the exact blur: 4.86 ns per wave-level (v_mul_f32, v_cvt_f64_f32, v_add_f64)
+        # triple per SIMD (tools/microbench_valu.hip), 1024 SIMDs
+        taps = 0
+        size = 2.0
+        for o in range(args.octaves):
+            for i in range(levels):
+                sig = 1.6 * (2.0 ** 0.5) ** i * (2.0 / size)
+                taps += px[o] * 2 * (int(round(6 * sig + 1)) | 1)
+            size /= 2.0
+        valu_floor_ms = taps / 64.0 / 1024.0 * 4.86e-6
         roofline = {
-            "kernel": "blur_row_kernel + blur_col_kernel (Gaussian pyramid + fused DoG, %d launches/frame)" % launches,
+            "kernel": "%s (dominant kernel by total time; %d launches/frame)" % (kname or dom, n_dom),
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
-            "algorithmic_bytes_per_frame": alg_pyr,
-            "ms_per_frame": round(t_pyr_ms, 4),
-            "avg_launch_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items() if v[1]},
+            "traffic": traffic,
+            "traffic_source": traffic_note,
+            "algorithmic_bytes_per_launch": round(alg_launch),
+            "avg_launch_ms": round(avg_ms, 5),
+            "pyramid_stage": {
+                "launches_per_frame": sum(prof[k][1] for k in blur_keys) // nprof,
+                "algorithmic_bytes_per_frame": alg_stage,
+                "ms_per_frame": round(t_stage, 4),
+                "achieved_GBps": round(alg_stage / (t_stage * 1e-3) / 1e9, 1),
+                "frac": round(alg_stage / (t_stage * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "valu_floor_ms": round(valu_floor_ms, 4) if args.blur_mode == 0 else None,
+                "frac_of_valu_floor": round(valu_floor_ms / t_stage, 4) if args.blur_mode == 0 else None,
+            },
+            "avg_launch_ms_by_class": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items() if v[1]},
             "stage_ms_per_frame": {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1]},
-            "note": "blur_mode 0 reproduces the reference's float-product/double-accumulate arithmetic and is "
-                    "VALU-bound (mul+cvt+f64 add per tap), not HBM-bound",
+            "note": "blur_mode 0 keeps the reference's float-product / double-accumulate arithmetic bit for bit, "
+                    "which makes the blur fp64-VALU-bound (v_mul_f32 + v_cvt_f64_f32 + v_add_f64 per tap), not "
+                    "HBM-bound; frac_of_valu_floor is the efficiency against that bound",
         }
 
     # ---- match leg ---------------------------------------------------------------------

@@ -145,7 +145,9 @@ enum {
     SIFT_HIP_K_DESCR = 7,
     SIFT_HIP_K_MATCH = 8,
     SIFT_HIP_K_GRAY = 9,
-    SIFT_HIP_K_COUNT = 10
+    SIFT_HIP_K_BLUR_ROW_SMALL = 10, /* the 2-outputs-per-thread variants used for small octaves */
+    SIFT_HIP_K_BLUR_COL_SMALL = 11,
+    SIFT_HIP_K_COUNT = 12
 };
 int sift_hip_profile(sift_hip_ctx* ctx, int enable);
 /* Synchronises, then fills ms[k] = summed kernel time and launches[k] = launch

@@ -272,7 +272,7 @@ template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                            const float* d_taps, int K) {
     {
-        ProfScope ps(ctx, SIFT_HIP_K_BLUR_ROW, st);
+        ProfScope ps(ctx, P == 8 ? SIFT_HIP_K_BLUR_ROW : SIFT_HIP_K_BLUR_ROW_SMALL, st);
         const int n_in = 64 * P + K - 1 + P;
         const size_t lds = (size_t)(n_in + n_in / P + 1) * sizeof(float);
         dim3 grid((W + 64 * P - 1) / (64 * P), H);
@@ -280,7 +280,7 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
                            K);
     }
     {
-        ProfScope ps(ctx, SIFT_HIP_K_BLUR_COL, st);
+        ProfScope ps(ctx, P == 8 ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
         int TH = 16 * P;
         while (TH > 4 * P && (size_t)(TH + K - 1 + P) * 256 > 48 * 1024) TH >>= 1;
