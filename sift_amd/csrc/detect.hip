@@ -54,28 +54,81 @@ __device__ __forceinline__ bool is_keypoint(const float* d, float v, float rad) 
 
 // grid = (ceil(W/64), ceil(H/DET_TR)).  Writes every mask word of its tile (zeros
 // included) and adds the per-(layer,row) counts into row_cnt (zeroed beforehand).
+template <int NLAY>  // intvls + 2 when known at compile time, else 0
 __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
                                                           int intvls, const LayerConsts* __restrict__ lc, float thr,
                                                           int WW, unsigned long long* __restrict__ masks,
                                                           int* __restrict__ row_cnt) {
     extern __shared__ float s_dog[];  // [intvls+2][DET_LH][DET_LW]
     constexpr int LS = DET_LH * DET_LW;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DET_TR;
+    // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.
+    // Remap so that one XCD owns a contiguous run of tiles: the halo columns and
+    // rows shared with the neighbouring tiles are then L2 hits instead of fabric
+    // reads (bijective for any tile count).
+    const int ntile = WW * gridDim.y;
+    const int bid = blockIdx.y * WW + blockIdx.x;
+    const int q8 = ntile >> 3, r8 = ntile & 7, xcd = bid & 7;
+    const int tid_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tx = tid_lin % WW, ty = tid_lin / WW;
+    const int x0 = tx * 64, y0 = ty * DET_TR;
     const int nlay = intvls + 2;
-    for (int t = threadIdx.x; t < LS; t += 256) {
-        const int ty = t / DET_LW, tx = t - ty * DET_LW;
-        const int gx = min(max(x0 + tx - 1, 0), W - 1);
-        const int gy = min(max(y0 + ty - 1, 0), H - 1);
-        const size_t q = (size_t)gy * W + gx;
-        float a = gau[q];
-        for (int k = 0; k < nlay; k++) {
-            const float b = gau[(size_t)(k + 1) * PX + q];
-            s_dog[k * LS + t] = a - b;
-            a = b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        // one wavefront per tile row: 64 coalesced columns + the two halo columns
+        // on lanes 0 and 1; every level is read once
+        const int gx = min(x0 + lane, W - 1);
+        const int hx = lane == 0 ? max(x0 - 1, 0) : min(x0 + 64, W - 1);
+        const int hcol = lane == 0 ? 0 : DET_LW - 1;
+        if (NLAY > 0) {
+            // all loads of the tile in flight at once
+            constexpr int NL = NLAY > 0 ? NLAY : 1;
+            constexpr int NR = (DET_LH + 3) / 4;
+            float v[NR][NL + 1], hv[NR][NL + 1];
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                const int r = wave + 4 * i;
+                const int gy = min(max(y0 + r - 1, 0), H - 1);
+                const float* row = gau + (size_t)gy * W;
+#pragma unroll
+                for (int k = 0; k <= NL; k++) {
+                    v[i][k] = row[(size_t)k * PX + gx];
+                    hv[i][k] = lane < 2 ? row[(size_t)k * PX + hx] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                const int r = wave + 4 * i;
+                if (r < DET_LH) {
+                    float* dst = s_dog + r * DET_LW;
+#pragma unroll
+                    for (int k = 0; k < NL; k++) {
+                        dst[k * LS + lane + 1] = v[i][k] - v[i][k + 1];
+                        if (lane < 2) dst[k * LS + hcol] = hv[i][k] - hv[i][k + 1];
+                    }
+                }
+            }
+        } else {
+            for (int r = wave; r < DET_LH; r += 4) {
+                const int gy = min(max(y0 + r - 1, 0), H - 1);
+                const float* row = gau + (size_t)gy * W;
+                float* dst = s_dog + r * DET_LW;
+                float a = row[gx];
+                float ha = lane < 2 ? row[hx] : 0.f;
+                for (int k = 0; k < nlay; k++) {
+                    row += PX;
+                    const float b = row[gx];
+                    dst[k * LS + lane + 1] = a - b;
+                    a = b;
+                    if (lane < 2) {
+                        const float hb = row[hx];
+                        dst[k * LS + hcol] = ha - hb;
+                        ha = hb;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = x0 + lane;
     for (int ry = wave; ry < DET_TR; ry += 4) {
         const int y = y0 + ry;
@@ -90,7 +143,7 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restric
             if (hit) hit = is_keypoint(d, v, (float)rad);
             const unsigned long long m = __ballot(hit);
             if (lane == 0) {
-                masks[((size_t)l * H + y) * WW + blockIdx.x] = m;
+                masks[((size_t)l * H + y) * WW + tx] = m;
                 if (m) atomicAdd(&row_cnt[l * H + y], __popcll(m));
             }
         }
@@ -352,7 +405,8 @@ void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
         ProfScope ps(ctx, SIFT_HIP_K_DETECT, ws.stream);
         hipMemsetAsync(ws.row_cnt.p, 0, (size_t)nrows * sizeof(int), ws.stream);
         const size_t lds = (size_t)(intvls + 2) * DET_LH * DET_LW * sizeof(float);
-        hipLaunchKernelGGL(detect_tile_kernel, dim3(WW, (H + DET_TR - 1) / DET_TR), dim3(256), lds, ws.stream,
+        auto kern = intvls == 3 ? detect_tile_kernel<5> : detect_tile_kernel<0>;
+        hipLaunchKernelGGL(kern, dim3(WW, (H + DET_TR - 1) / DET_TR), dim3(256), lds, ws.stream,
                            (const float*)ws.gau_all.p, PX, W, H, intvls, d_lc, thr, WW,
                            (unsigned long long*)ws.masks.p, (int*)ws.row_cnt.p);
     }
