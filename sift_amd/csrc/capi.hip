@@ -134,6 +134,23 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
     // cos/sin of the 36 possible orientations, taken in DEGREES as radians (Sift.cpp:351-352)
     for (int k = 0; k < 36; k++) pl.table.push_back(std::cos((float)(k * 10)));
     for (int k = 0; k < 36; k++) pl.table.push_back(std::sin((float)(k * 10)));
+    // Sift.cpp:369-372 wraps (gradient angle - ori) into [0, 2*pi) by repeated float
+    // additions of 2*pi; with ori up to 350 that is up to 56 roundings on a coarse
+    // grid.  The net shift those additions give an angle of 0 is tabulated per
+    // orientation as a two-float constant; the kernel adds it in one step.
+    {
+        const float PI2 = (float)(2.f * 3.14159265358979323846);
+        double shift[36];
+        for (int k = 0; k < 36; k++) {
+            const float x0 = 0.f - (float)(k * 10);
+            float x = x0;
+            while (x < 0.f) x += PI2;
+            while (x >= PI2) x -= PI2;
+            shift[k] = (double)x - (double)x0;
+        }
+        for (int k = 0; k < 36; k++) pl.table.push_back((float)shift[k]);
+        for (int k = 0; k < 36; k++) pl.table.push_back((float)(shift[k] - (double)(float)shift[k]));
+    }
     float curr_size = 2.f, coef = 1.f;
     for (int ph = 0; ph < octvs; ph++, curr_size /= 2.f, coef *= 2.f) {
         OctavePlan oc;
@@ -358,6 +375,8 @@ static int extract_dev_impl(sift_hip_ctx* ctx, const float* d_gray, int w, int h
     if (params) prm = *params; else sift_hip_default_params(&prm);
     if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || prm.octaves > 24 || !(prm.sigma0 > 0.f))
         return SIFT_HIP_ERR_ARG;
+    // octave 0 is the image doubled in both directions; the kernels index one level with 32 bits
+    if ((long long)w * h * 4 >= (1ll << 31)) return SIFT_HIP_ERR_LIMIT;
     int cand_cap = std::max(ctx->cand_cap, std::max(cap, 1 << 16));
     for (int attempt = 0; attempt < 4; attempt++) {
         ctx->cand_cap = cand_cap;

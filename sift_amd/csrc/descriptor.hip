@@ -5,143 +5,227 @@
 // (Sift.cpp:299-421) expression by expression, including that the orientation in
 // DEGREES is used as a radian angle and that both normalize_descr calls are
 // no-ops (feat->d is still 0 there), so the descriptor is the clamped raw
-// histogram times 512.  atan2f/expf come from the device math library and the
-// bin sums are exact fixed-point sums rather than the reference's sequential
-// float additions, so the histogram matches to rounding (~1e-6 relative), not
-// bit for bit.
+// histogram times 512.  atan2/exp/sqrt are hardware-rate approximations (2e-7 rad,
+// 1 ulp), divisions by the bin width are multiplications by its reciprocal and
+// the bin sums are fixed-point sums rather than the reference's sequential float
+// additions, so the histogram matches to ~1e-6 relative, not bit for bit.
 #include <algorithm>
 
 #include "internal.h"
 
 namespace sifthip {
 
-// The bins are accumulated in LDS as 64-bit fixed point (2^-40 units) with integer
+// The bins are accumulated in LDS as 64-bit fixed point (2^-30 units) with integer
 // atomics: on gfx950 a ds_add_f32 costs ~170 cycles per wave-instruction against
 // ~6 for ds_add_u32 (measured, tools/microbench_lds.hip), and the integer sum is
 // independent of the order in which lanes and waves arrive, so the result is
-// deterministic and within 2^-41 per addend of the exact sum.  The 128 bins
-// exist NCOPY times (copy = thread mod NCOPY, odd row stride) because the
-// samples a wave handles together are neighbours in the window and mostly hit
-// the same few bins.
+// deterministic.  The 128 bins exist NCOPY times (copy = thread mod NCOPY, odd
+// row stride) because the samples a wave handles together are neighbours in the
+// window and mostly hit the same few bins.
 constexpr int NCOPY = 8;
 constexpr int HSTRIDE = 129;
-constexpr float kFixHi = 256.f;          // 2^8
-constexpr float kFixLo = 4294967296.f;   // 2^32  (2^8 * 2^32 = 2^40 units per 1.0)
+constexpr float kFixScale = 1073741824.f;  // 2^30 units per 1.0; one addend is < 4
+constexpr int RCH = 1024;                  // window rows handled per pass
+constexpr int DU = 4;                      // samples in flight per thread
 
-__device__ __forceinline__ unsigned long long to_fixed40(float v) {
-    const float t = v * kFixHi;              // exact
-    const unsigned hi = (unsigned)t;         // v < 2^16 here, so (float)hi below is exact
-    const float fr = t - (float)hi;          // exact, in [0,1)
-    const unsigned lo = (unsigned)(fr * kFixLo);
-    return ((unsigned long long)hi << 32) | lo;
+// v is already scaled by kFixScale
+__device__ __forceinline__ unsigned long long to_fixed30(float v) { return (unsigned long long)(unsigned)v; }
+
+// atan2 in (-pi, pi] from a degree-15 odd polynomial on [0,1] (max error 2e-7 rad).
+__device__ __forceinline__ float atan2_poly(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+    const float s = a * a;
+    float p = -0.004780722316354513f;
+    p = fmaf(p, s, 0.024558117613196373f);
+    p = fmaf(p, s, -0.059906188398599625f);
+    p = fmaf(p, s, 0.0994287058711052f);
+    p = fmaf(p, s, -0.1402946412563324f);
+    p = fmaf(p, s, 0.1997138410806656f);
+    p = fmaf(p, s, -0.3333209455013275f);
+    p = fmaf(p, s, 0.9999999403953552f);
+    float t = p * a;
+    if (ay > ax) t = 1.57079632679489662f - t;
+    if (x < 0.f) t = 3.14159265358979324f - t;
+    return y < 0.f ? -t : t;
 }
 
+// Tightens the inclusive column range [jlo, jhi] of a window row to a superset of
+// the columns with |j*p + q| < L.
+__device__ __forceinline__ void clip_row(int& jlo, int& jhi, float p, float q, float L) {
+    if (fabsf(p) > 1e-3f) {
+        const float inv = 1.f / p;
+        const float a = (-L - q) * inv, b = (L - q) * inv;
+        jlo = max(jlo, (int)floorf(fminf(a, b)));
+        jhi = min(jhi, (int)ceilf(fmaxf(a, b)));
+    }
+}
+
+// cs: cos[36], sin[36] of the orientation (degrees read as radians), then the
+// two-float wrap constant of each orientation (see build_plan).
 __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
                                                    const float* __restrict__ cs, sift_hip_feat* __restrict__ feat,
                                                    int feat_cap, const int* __restrict__ counters,
                                                    float* __restrict__ hist_out) {
     __shared__ unsigned long long hist[NCOPY * HSTRIDE];
+    __shared__ int s_off[RCH + 1];  // first sample number of each window row of the pass
+    __shared__ int s_lo[RCH];       // first column of each row
     // blockDim.x (a multiple of 64, chosen per octave from the window size) threads
     // share one feature; windows grow with the octave up to (2*382+1)^2 samples
     const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63;
     unsigned long long* myhist = hist + (tid & (NCOPY - 1)) * HSTRIDE;
-    const int begin = counters[CNT_OCT_BEGIN];
     const int end = min(counters[CNT_OCT_END], feat_cap);
     const float PI2 = (float)(2.f * 3.14159265358979323846);
     const float bins_per_rad = 8 / PI2;
-    const float exp_denom = 4 * 4 * 0.5f;
-    for (int fi = begin + blockIdx.x; fi < end; fi += gridDim.x) {
+    const float exp_scale = -1.44269504088896341f / (4 * 4 * 0.5f);  // exp(-x/8) = 2^(x * exp_scale)
+    // (A work queue on one global counter is no alternative: atomics on a single
+    // address retire at ~13 ns each on this part, more than a feature costs.)
+    for (int fi = counters[CNT_OCT_BEGIN] + blockIdx.x; fi < end; fi += gridDim.x) {
         const sift_hip_feat* f = feat + fi;
         const int kai = f->kai, r = f->y, c = f->x, sita = f->sita;
         const float ori = (float)sita;
         const float scl = (float)(int)f->sigmaOCT;
         const float* img = gau + (size_t)kai * PX;
         for (int t = tid; t < NCOPY * HSTRIDE; t += nthr) hist[t] = 0ull;
-        __syncthreads();
-        const float cos_t = cs[sita / 10];
-        const float sin_t = cs[36 + sita / 10];
+        const int ob36 = sita / 10;
+        const float cos_t = cs[ob36];
+        const float sin_t = cs[36 + ob36];
+        // The reference brings atan2 - ori (ori up to 350 "radians") into [0, 2*pi)
+        // by adding 2*pi one float addition at a time (Sift.cpp:369-372); the sum of
+        // those roundings for this orientation is folded into wrap_hi + wrap_lo.
+        const float wrap_hi = cs[72 + ob36], wrap_lo = cs[108 + ob36];
         const float hist_width = 3.f * scl;
+        const float inv_hw = 1.f / hist_width;
+        const float L = 2.5f * hist_width;
         const int radius = (int)(hist_width * sqrtf(2.f) * (4 + 1.f) * 0.5f + 0.5f);
-        // every sample needs at least `pre` additions of 2*pi to leave the negatives
-        int pre = (int)floorf((ori - 3.2f) / 6.2831855f) - 1;
-        if (pre < 0) pre = 0;
-        // the (2*radius+1)^2 window, flattened row-major over the 64 lanes
         const int n = 2 * radius + 1;
-        const int total = n * n;
-        const int di = nthr / n, dj = nthr - di * n;
-        int wi = tid / n;
-        int wj = tid - wi * n;
-        for (int idx = tid; idx < total; idx += nthr) {
-            const int i = wi - radius, j = wj - radius;
-            wj += dj;
-            wi += di;
-            if (wj >= n) {
-                wj -= n;
-                wi++;
+        for (int row0 = 0; row0 < n; row0 += RCH) {
+            const int nr = min(RCH, n - row0);
+            if (tid < 64) {
+                // Row ranges: only columns inside the image interior (calc_grad_mag_ori,
+                // Sift.cpp:299-311) and inside the rotated 4x4 grid can contribute.
+                int running = 0;
+                for (int b = 0; b < nr; b += 64) {
+                    const int row = b + lane;
+                    int jlo = 0, len = 0;
+                    if (row < nr) {
+                        const int i = row0 + row - radius;
+                        const int rr = r + i;
+                        if (rr > 0 && rr < H - 1) {
+                            int jhi = min(radius, W - 2 - c);
+                            jlo = max(-radius, 1 - c);
+                            clip_row(jlo, jhi, sin_t, (float)i * cos_t, L);
+                            clip_row(jlo, jhi, cos_t, -(float)i * sin_t, L);
+                            len = max(0, jhi - jlo + 1);
+                        }
+                    }
+                    int inc = len;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int t = __shfl_up(inc, o);
+                        if (lane >= o) inc += t;
+                    }
+                    if (row < nr) {
+                        s_off[row] = running + inc - len;
+                        s_lo[row] = jlo;
+                    }
+                    running += __shfl(inc, 63);
+                }
+                if (lane == 0) s_off[nr] = running;
             }
-            const int rr = r + i, cc = c + j;
-            if (rr <= 0 || rr >= H - 1 || cc <= 0 || cc >= W - 1) continue;  // calc_grad_mag_ori rejects it
-            const float c_rot = ((float)j * cos_t - (float)i * sin_t) / hist_width;
-            const float r_rot = ((float)j * sin_t + (float)i * cos_t) / hist_width;
-            const float rbin = r_rot + 4 / 2.f - 0.5f;
-            const float cbin = c_rot + 4 / 2.f - 0.5f;
-            if (!(rbin > -1.f && rbin < 4.f && cbin > -1.f && cbin < 4.f)) continue;
-            const size_t p = (size_t)rr * W + cc;
-            const float dx = img[p + 1] - img[p - 1];
-            const float dy = img[p - W] - img[p + W];
-            const float mag = sqrtf(dx * dx + dy * dy);
-            float go = atan2f(dy, dx);
-            go -= ori;
-            for (int t = 0; t < pre; t++) go += PI2;
-            while (go < 0.f) go += PI2;
-            while (go >= PI2) go -= PI2;
-            const float obin = go * bins_per_rad;
-            const float w = expf(-(c_rot * c_rot + r_rot * r_rot) / exp_denom);
-            const float m = mag * w;
-            // interp_hist_entry
-            const float fr0 = floorf(rbin), fc0 = floorf(cbin), fo0 = floorf(obin);
-            const int r0 = (int)fr0, c0 = (int)fc0, o0 = (int)fo0;
-            const float d_r = rbin - fr0, d_c = cbin - fc0, d_o = obin - fo0;
+            __syncthreads();
+            const int total = s_off[nr];
+            int row = 0;
+            // DU samples per thread and step: their 4*DU gradient loads are issued
+            // before any of them is consumed (the loop is otherwise bound by the
+            // latency of one gather per wave)
+            for (int idx0 = tid; idx0 < total; idx0 += DU * nthr) {
+                float px[DU][4], rb_[DU], cb_[DU], ww[DU];
+                bool ok[DU];
 #pragma unroll
-            for (int a = 0; a <= 1; a++) {
-                const int rb = r0 + a;
-                if (rb >= 0 && rb < 4) {
-                    const float v_r = m * ((a == 0) ? 1.f - d_r : d_r);
+                for (int u = 0; u < DU; u++) {
+                    const int idx = idx0 + u * nthr;
+                    ok[u] = idx < total;
+                    if (ok[u]) {
+                        while (idx >= s_off[row + 1]) row++;
+                        const int i = row0 + row - radius;
+                        const int j = s_lo[row] + idx - s_off[row];
+                        const float fi_ = (float)i, fj = (float)j;
+                        const float c_rot = (fj * cos_t - fi_ * sin_t) * inv_hw;
+                        const float r_rot = (fj * sin_t + fi_ * cos_t) * inv_hw;
+                        rb_[u] = r_rot + 4 / 2.f - 0.5f;
+                        cb_[u] = c_rot + 4 / 2.f - 0.5f;
+                        ww[u] = c_rot * c_rot + r_rot * r_rot;
+                        ok[u] = rb_[u] > -1.f && rb_[u] < 4.f && cb_[u] > -1.f && cb_[u] < 4.f;
+                        if (ok[u]) {
+                            const unsigned p = (unsigned)((r + i) * W + (c + j));  // one level holds < 2^31 floats
+                            px[u][0] = img[p + 1u];
+                            px[u][1] = img[p - 1u];
+                            px[u][2] = img[p - (unsigned)W];
+                            px[u][3] = img[p + (unsigned)W];
+                        }
+                    }
+                }
 #pragma unroll
-                    for (int b = 0; b <= 1; b++) {
-                        const int cb = c0 + b;
-                        if (cb >= 0 && cb < 4) {
-                            const float v_c = v_r * ((b == 0) ? 1.f - d_c : d_c);
+                for (int u = 0; u < DU; u++) {
+                    if (!ok[u]) continue;
+                    const float rbin = rb_[u], cbin = cb_[u];
+                    const float dx = px[u][0] - px[u][1];
+                    const float dy = px[u][2] - px[u][3];
+                    const float mag = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+                    float go = atan2_poly(dy, dx) - ori;
+                    go = (go + wrap_hi) + wrap_lo;
+                    if (go < 0.f) go += PI2;
+                    if (go >= PI2) go -= PI2;
+                    const float obin = go * bins_per_rad;
+                    const float w = __builtin_amdgcn_exp2f(ww[u] * exp_scale);
+                    const float m = mag * w * kFixScale;  // exact scaling by 2^30
+                    // interp_hist_entry (Sift.cpp:313-343)
+                    const float fr0 = floorf(rbin), fc0 = floorf(cbin), fo0 = floorf(obin);
+                    const int r0 = (int)fr0, c0 = (int)fc0, o0 = (int)fo0;
+                    const float d_r = rbin - fr0, d_c = cbin - fc0, d_o = obin - fo0;
+                    unsigned long long* hb = myhist + (r0 * 4 + c0) * 8;
+                    const int ob0 = o0 & 7, ob1 = (o0 + 1) & 7;
 #pragma unroll
-                            for (int o = 0; o <= 1; o++) {
-                                const int ob = (o0 + o) & 7;
-                                const float v_o = v_c * ((o == 0) ? 1.f - d_o : d_o);
-                                atomicAdd(&myhist[(rb * 4 + cb) * 8 + ob], to_fixed40(v_o));
+                    for (int a = 0; a <= 1; a++) {
+                        const int rb = r0 + a;
+                        if (rb >= 0 && rb < 4) {
+                            const float v_r = m * ((a == 0) ? 1.f - d_r : d_r);
+#pragma unroll
+                            for (int b = 0; b <= 1; b++) {
+                                const int cb = c0 + b;
+                                if (cb >= 0 && cb < 4) {
+                                    const float v_c = v_r * ((b == 0) ? 1.f - d_c : d_c);
+                                    atomicAdd(&hb[(a * 4 + b) * 8 + ob0], to_fixed30(v_c * (1.f - d_o)));
+                                    atomicAdd(&hb[(a * 4 + b) * 8 + ob1], to_fixed30(v_c * d_o));
+                                }
                             }
                         }
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         // hist_to_descr: clamp at 0.2 (double compare), x512 in double, truncate, min 255
         if (tid < 64) {
-        unsigned char q[2];
+            unsigned char q[2];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int b = tid * 2 + t;
-            unsigned long long acc = 0ull;
+            for (int t = 0; t < 2; t++) {
+                const int b = tid * 2 + t;
+                unsigned long long acc = 0ull;
 #pragma unroll
-            for (int k = 0; k < NCOPY; k++) acc += hist[k * HSTRIDE + b];
-            float hv = (float)((double)acc * (1.0 / 1099511627776.0));
-            if ((double)hv > 0.2) hv = (float)0.2;
-            if (hist_out) hist_out[(size_t)fi * 128 + b] = hv;
-            const int iv = (int)(512.0 * (double)hv);
-            q[t] = (unsigned char)min(255, iv);
-        }
-        unsigned char* d = feat[fi].descr + tid * 2;
-        d[0] = q[0];
-        d[1] = q[1];
+                for (int k = 0; k < NCOPY; k++) acc += hist[k * HSTRIDE + b];
+                float hv = (float)((double)acc * (1.0 / 1073741824.0));
+                if ((double)hv > 0.2) hv = (float)0.2;
+                if (hist_out) hist_out[(size_t)fi * 128 + b] = hv;
+                const int iv = (int)(512.0 * (double)hv);
+                q[t] = (unsigned char)min(255, iv);
+            }
+            unsigned char* d = feat[fi].descr + tid * 2;
+            d[0] = q[0];
+            d[1] = q[1];
         }
         __syncthreads();
     }
