@@ -2,8 +2,8 @@
 
 Bars: bit-exact for the pyramid (blur_mode 0), keypoint records (position, layer,
 orientation bin, mm) and match indices/distances; descriptors within L2 1e-3 of
-the oracle's clamped histogram (device atan2f/expf and a different summation
-order), bytes within +-1.
+the oracle's clamped histogram (hardware-rate atan2/exp/sqrt and fixed-point bin
+sums instead of sequential float additions), bytes within +-1.
 """
 import numpy as np
 import pytest
