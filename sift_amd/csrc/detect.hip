@@ -240,16 +240,13 @@ __device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
     const float p7 = -0.04432655554792128f * k;
     const float eps = (float)2.2204460492503131e-016;
     const float ax = fabsf(dx), ay = fabsf(dy);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + eps);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + eps);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // both branches of the reference evaluate the same polynomial in min/(max + eps);
+    // selecting the operands first leaves one division for the whole wavefront
+    const bool xmaj = ax >= ay;
+    const float c = (xmaj ? ay : ax) / ((xmaj ? ax : ay) + eps);
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (!xmaj) a = 90.f - a;
     if (dx < 0) a = 180.f - a;
     if (dy < 0) a = 360.f - a;
     return a;
@@ -259,9 +256,20 @@ __device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
 // One wavefront per candidate.  The reference adds the weighted magnitudes into
 // the 36 bins one window pixel after another (row-major); float addition is not
 // associative and the ">= 0.8 * max" test decides how many features a keypoint
-// becomes, so the order is kept: the window is evaluated in parallel into LDS in
-// chunks, then lane b walks the chunk in order and adds the entries of bin b.
-constexpr int ORI_CH = 2048;
+// becomes, so the order of the additions is kept.  Per pass of ORI_CH window
+// pixels:
+//   A  all lanes evaluate magnitude and bin of their pixels (strided, coalesced)
+//   B  a stable counting sort by bin: lane l owns the ORI_RUN consecutive pixels
+//      16l..16l+15, counts them per bin with LDS atomics, lane b turns row b of
+//      the (bin x lane) count matrix into running offsets, and the pixels are
+//      scattered to (bin, lane, rank) order -- window order within each bin
+//   C  lane b adds the values of bin b front to back.
+// Lane b touches only its own ~1/36 of the pixels instead of testing every pixel
+// against its bin number.
+constexpr int ORI_CH = 1024;
+constexpr int ORI_RUN = 16;
+constexpr int AU = 4;
+constexpr int ORI_ROW = 33;  // dwords per count-matrix row: 32 lane pairs (two u16 each) + 1 pad
 
 // floor(th / 10) for th in [0, 360]: what (size_t)(sita / 10.0) yields in double
 // arithmetic (th / 10.0 is never within rounding distance of an integer unless th
@@ -279,10 +287,15 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
                                                     const float* __restrict__ table, const Cand* __restrict__ cand,
                                                     const int* __restrict__ counters,
                                                     unsigned long long* __restrict__ cmask, float* __restrict__ cmm) {
-    __shared__ __attribute__((aligned(16))) float s_val[ORI_CH];
-    __shared__ __attribute__((aligned(16))) unsigned char s_bin[ORI_CH];
+    __shared__ float s_val[ORI_CH + ORI_CH / ORI_RUN];                      // pixel e at e + e/16
+    __shared__ unsigned s_binw[64 * 5];                                     // bin of pixel e: byte (e/16)*20 + e%16
+    __shared__ __attribute__((aligned(16))) unsigned s_cnt[37 * ORI_ROW + 59];  // 1280 dwords
+    __shared__ float s_sorted[ORI_CH];
+    __shared__ int s_base[36];
+    unsigned char* s_bin = reinterpret_cast<unsigned char*>(s_binw);
     const int lane = threadIdx.x;
     const int ncand = counters[CNT_NCAND];
+    const unsigned half_shift = (lane & 1) * 16;
     for (int ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
         const Cand cd = cand[ci];
         const LayerConsts L = lc[cd.layer - 1];
@@ -299,35 +312,106 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
         float sum = 0.f;
         for (int e0 = 0; e0 < total; e0 += ORI_CH) {
             const int cnt = min(ORI_CH, total - e0);
-            for (int e = lane; e < cnt; e += 64) {
-                const size_t p = (size_t)(cd.y - r + jj) * W + (cd.x - r + ii);
-                const float dx = (g1[p + 1] - g2[p + 1]) - (g1[p - 1] - g2[p - 1]);
-                const float dy = (g1[p + W] - g2[p + W]) - (g1[p - W] - g2[p - W]);
-                float mag = sqrtf(dx * dx + dy * dy);
-                const float th = fast_atan2f_deg(dy, dx);
-                mag = mag * g[ii];
-                mag = mag * g[jj];
-                s_val[e] = mag;
-                s_bin[e] = (unsigned char)angle_bin(th);  // 36 == "one past the end": dropped
-                ii += dj;
-                jj += di;
-                if (ii >= n) {
-                    ii -= n;
-                    jj++;
+            // ---- A: magnitude and bin of every pixel of the pass
+            // (AU pixels per lane and step: their 8*AU loads are issued before any is used)
+            for (int eb = lane; eb < cnt; eb += 64 * AU) {
+                float q[AU][8], wgt_i[AU], wgt_j[AU];
+#pragma unroll
+                for (int u = 0; u < AU; u++) {
+                    if (eb + 64 * u < cnt) {
+                        const unsigned p = (unsigned)((cd.y - r + jj) * W + (cd.x - r + ii));
+                        q[u][0] = g1[p + 1u];
+                        q[u][1] = g2[p + 1u];
+                        q[u][2] = g1[p - 1u];
+                        q[u][3] = g2[p - 1u];
+                        q[u][4] = g1[p + (unsigned)W];
+                        q[u][5] = g2[p + (unsigned)W];
+                        q[u][6] = g1[p - (unsigned)W];
+                        q[u][7] = g2[p - (unsigned)W];
+                        wgt_i[u] = g[ii];
+                        wgt_j[u] = g[jj];
+                        ii += dj;
+                        jj += di;
+                        if (ii >= n) {
+                            ii -= n;
+                            jj++;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < AU; u++) {
+                    const int e = eb + 64 * u;
+                    if (e < cnt) {
+                        const float dx = (q[u][0] - q[u][1]) - (q[u][2] - q[u][3]);
+                        const float dy = (q[u][4] - q[u][5]) - (q[u][6] - q[u][7]);
+                        float mag = sqrtf(dx * dx + dy * dy);
+                        const float th = fast_atan2f_deg(dy, dx);
+                        mag = mag * wgt_i[u];
+                        mag = mag * wgt_j[u];
+                        s_val[e + (e >> 4)] = mag;
+                        s_bin[(e >> 4) * 20 + (e & 15)] = (unsigned char)angle_bin(th);  // 36 == "one past the end": dropped
+                    }
+                }
+            }
+            {
+                uint4* z = reinterpret_cast<uint4*>(s_cnt);
+#pragma unroll
+                for (int i = 0; i < 5; i++) z[i * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+            // ---- B1: per-(bin, lane) counts of the lane's run of 16 pixels
+            unsigned bw[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) bw[i] = s_binw[lane * 5 + i];
+            const int run0 = lane * ORI_RUN;
+#pragma unroll
+            for (int t = 0; t < ORI_RUN; t++) {
+                const unsigned b = (bw[t >> 2] >> ((t & 3) * 8)) & 0xffu;
+                if (run0 + t < cnt && b < 36u) atomicAdd(&s_cnt[b * ORI_ROW + (lane >> 1)], 1u << half_shift);
+            }
+            __syncthreads();
+            // ---- B2: lane b turns row b into running offsets (lane order), then the
+            // bins' totals into bin bases
+            int my_total = 0;
+            if (lane < 36) {
+                unsigned* rowp = s_cnt + lane * ORI_ROW;
+                unsigned run = 0;
+#pragma unroll 8
+                for (int i = 0; i < 32; i++) {
+                    const unsigned wv = rowp[i];
+                    const unsigned lo = wv & 0xffffu, hi = wv >> 16;
+                    rowp[i] = run | ((run + lo) << 16);
+                    run += lo + hi;
+                }
+                my_total = (int)run;
+            }
+            int inc = my_total;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            const int my_start = inc - my_total;
+            if (lane < 36) s_base[lane] = my_start;
+            __syncthreads();
+            // ---- B3: scatter to (bin, lane, rank) order
+#pragma unroll
+            for (int t = 0; t < ORI_RUN; t++) {
+                const unsigned b = (bw[t >> 2] >> ((t & 3) * 8)) & 0xffu;
+                if (run0 + t < cnt && b < 36u) {
+                    const unsigned old = atomicAdd(&s_cnt[b * ORI_ROW + (lane >> 1)], 1u << half_shift);
+                    const int pos = s_base[b] + (int)((old >> half_shift) & 0xffffu);
+                    s_sorted[pos] = s_val[lane * (ORI_RUN + 1) + t];
                 }
             }
             __syncthreads();
-            if (lane < 36) {
-                int e = 0;
-                for (; e + 4 <= cnt; e += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(&s_val[e]);
-                    const unsigned b4 = *reinterpret_cast<const unsigned*>(&s_bin[e]);
-                    sum += ((b4 & 0xffu) == (unsigned)lane) ? v.x : 0.f;
-                    sum += (((b4 >> 8) & 0xffu) == (unsigned)lane) ? v.y : 0.f;
-                    sum += (((b4 >> 16) & 0xffu) == (unsigned)lane) ? v.z : 0.f;
-                    sum += ((b4 >> 24) == (unsigned)lane) ? v.w : 0.f;
-                }
-                for (; e < cnt; e++) sum += (s_bin[e] == lane) ? s_val[e] : 0.f;
+            // ---- C: ordered sums, four LDS reads in flight
+            for (int it = 0; __any(it < my_total && lane < 36); it += 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = (lane < 36 && it + u < my_total) ? s_sorted[my_start + it + u] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; u++) sum += v[u];
             }
             __syncthreads();
         }
