@@ -43,7 +43,10 @@ typedef struct sift_hip_params {
     float sigma0;        /* SIFT_GauSigma (1.6f) */
     float dx_thr;        /* SIFT_Dx (0.03f); the contrast test is |D| > dx_thr / 2 */
     int32_t subpixel;    /* 0 = off, as shipped by the reference (call commented out at Sift.cpp:187);
-                            1 = Lowe refinement of matrix.hpp:140-196 rejects/relocates candidates */
+                            1 = every candidate goes through interp_extremum (matrix.hpp:140-196): dropped
+                            where that returns nullptr, else moved to the refined (layer, row, column),
+                            which must still hold that layer's orientation window (Sift.cpp:178-179);
+                            the offsets are read with sift_hip_last_offsets */
     int32_t blur_mode;   /* 0 = exact: float product, double accumulation in tap order
                             (imglib/imglib.cpp:85-117); 1 = fast: fp32 FMA accumulation */
     float contr_thr;     /* SIFT_CONTR_THR (0.05), used only when subpixel = 1 */
@@ -96,6 +99,14 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
 /* Device-resident variant of the batch call: frames in device memory. */
 int sift_hip_extract_batch_dev(sift_hip_ctx* ctx, const float* d_frames, int w, int h, int nframes,
                                const sift_hip_params* params, sift_hip_feat* out, int cap, int* n);
+
+/* Sub-pixel offsets (xc, xr, xi of interp_extremum, matrix.hpp:154-194) of the features
+ * that the last extract call on this context returned, three floats per feature in
+ * output order; the refined position is (x + xc, y + yr) in octave pixels, i.e.
+ * ((x + xc) / size, (y + xr) / size) in the source image (matrix.hpp:188-189).  Returns
+ * the number of features written (at most cap); 0 if that call ran with subpixel = 0.
+ * After a batch call it covers the last frame only. */
+int sift_hip_last_offsets(sift_hip_ctx* ctx, float* xyz, int cap);
 
 /* ---- image ops kept public by the reference (imglib/imglib.hpp:18-57) ----------- */
 /* Gaus::gau_matrix, imglib.cpp:127-155 (host arithmetic, no GPU work). Returns the

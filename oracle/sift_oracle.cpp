@@ -196,6 +196,7 @@ struct Feat {  // the fields of Sift/imagedata.hpp:63-86 that the path fills
     int sita;
     float hist[128];   // clamped raw histogram ("before quantisation")
     float descr[128];  // integer-valued descriptor
+    float sub[3];      // sub-pixel offsets (xc, xr, xi) when the refinement is on, else 0
 };
 
 // Sift/Sift.cpp:86-104  findMaxMin
@@ -233,7 +234,7 @@ bool harris_corner(const Img& p, size_t w, size_t y, size_t x, float r) {
 
 // Sift/Sift.cpp:250-295  getHistogramMS + FeatAppend (:229-249)
 void histogram_ms(std::vector<Feat>& out, const Img& img, size_t W, float Insize, size_t intvl_idx,
-                  float sigma, size_t Iny, size_t Inx, size_t Inr) {
+                  float sigma, size_t Iny, size_t Inx, size_t Inr, const float* sub = nullptr) {
     const size_t matLen = Inr * 2 + 1;
     std::vector<float> mag(matLen * matLen);
     std::vector<float> sita(matLen * matLen);
@@ -269,6 +270,7 @@ void histogram_ms(std::vector<Feat>& out, const Img& img, size_t W, float Insize
             f.size = Insize;
             f.kai = (int)intvl_idx;
             f.sigmaOCT = (float)(int)sigma;  // FeatAppend takes sigmaOCT as int
+            if (sub) std::memcpy(f.sub, sub, sizeof f.sub);
             out.push_back(f);
         }
     }
@@ -359,6 +361,106 @@ void hist_to_descr(Feat& f) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Sift/matrix.hpp:12-196  Lowe's sub-pixel refinement.  DEAD CODE in the reference
+// (the header is included by no translation unit and the only call, Sift.cpp:187,
+// is commented out with its row/column arguments mixed up), so nothing can pin
+// it; it is restated expression by expression for the optional refinement stage.
+constexpr int kMaxInterpSteps = 5;  // SIFT_MAX_INTERP_STEPS
+constexpr int kImgBorder = 5;       // SIFT_IMG_BORDER
+
+// matrix.hpp:12-33
+void deriv_3d(const std::vector<Img>& dog, int Col, int intvl, int r, int c, float dI[3]) {
+    dI[0] = (dog[intvl][r * Col + (c + 1)] - dog[intvl][r * Col + (c - 1)]) / 2.f;
+    dI[1] = (dog[intvl][(r + 1) * Col + c] - dog[intvl][(r - 1) * Col + c]) / 2.f;
+    dI[2] = (dog[intvl + 1][r * Col + c] - dog[intvl - 1][r * Col + c]) / 2.f;
+}
+
+// matrix.hpp:34-67
+void hessian_3d(const std::vector<Img>& dog, int Col, int intvl, int r, int c, float H[9]) {
+    const Img& d0 = dog[intvl - 1];
+    const Img& d1 = dog[intvl];
+    const Img& d2 = dog[intvl + 1];
+    const float v = d1[r * Col + c];
+    const float dxx = (d1[r * Col + (c + 1)] + d1[r * Col + (c - 1)] - 2.f * v);
+    const float dyy = (d1[(r + 1) * Col + c] + d1[(r - 1) * Col + c] - 2.f * v);
+    const float dss = (d2[r * Col + c] + d0[r * Col + c] - 2.f * v);
+    const float dxy = (d1[(r + 1) * Col + (c + 1)] - d1[(r + 1) * Col + (c - 1)] - d1[(r - 1) * Col + (c + 1)] +
+                       d1[(r - 1) * Col + (c - 1)]) / 4.f;
+    const float dxs = (d2[r * Col + (c + 1)] - d2[r * Col + (c - 1)] - d0[r * Col + (c + 1)] +
+                       d0[r * Col + (c - 1)]) / 4.f;
+    const float dys = (d2[(r + 1) * Col + c] - d2[(r - 1) * Col + c] - d0[(r + 1) * Col + c] +
+                       d0[(r - 1) * Col + c]) / 4.f;
+    H[0] = dxx; H[1] = dxy; H[2] = dxs;
+    H[3] = dxy; H[4] = dyy; H[5] = dys;
+    H[6] = dxs; H[7] = dys; H[8] = dss;
+}
+
+// matrix.hpp:68-86
+void invert_3x3(const float v[9], float m[9]) {
+    float det_v = v[0] * (v[4] * v[8] - v[5] * v[7]);
+    det_v -= v[3] * (v[1] * v[8] - v[2] * v[7]);
+    det_v += v[6] * (v[1] * v[5] - v[2] * v[4]);
+    m[0] = 1 * (v[4] * v[8] - v[5] * v[7]) / det_v;
+    m[1] = -1 * (v[1] * v[8] - v[2] * v[7]) / det_v;
+    m[2] = 1 * (v[1] * v[5] - v[2] * v[4]) / det_v;
+    m[3] = -1 * (v[3] * v[8] - v[5] * v[6]) / det_v;
+    m[4] = 1 * (v[0] * v[8] - v[2] * v[6]) / det_v;
+    m[5] = -1 * (v[0] * v[5] - v[2] * v[3]) / det_v;
+    m[6] = 1 * (v[3] * v[7] - v[4] * v[6]) / det_v;
+    m[7] = -1 * (v[0] * v[7] - v[1] * v[6]) / det_v;
+    m[8] = 1 * (v[0] * v[4] - v[1] * v[3]) / det_v;
+}
+
+// matrix.hpp:102-112 (GEMM_3X1 with alpha = -1, :87-96)
+void interp_step(const std::vector<Img>& dog, int Col, int intvl, int r, int c, float& xi, float& xr, float& xc) {
+    float dD[3], H[9], Hi[9];
+    deriv_3d(dog, Col, intvl, r, c, dD);
+    hessian_3d(dog, Col, intvl, r, c, H);
+    invert_3x3(H, Hi);
+    const float alpha = -1.0;
+    xc = (Hi[0] * dD[0] + Hi[1] * dD[1] + Hi[2] * dD[2]) * alpha;
+    xr = (Hi[3] * dD[0] + Hi[4] * dD[1] + Hi[5] * dD[2]) * alpha;
+    xi = (Hi[6] * dD[0] + Hi[7] * dD[1] + Hi[8] * dD[2]) * alpha;
+}
+
+// matrix.hpp:113-124
+float interp_contr(const std::vector<Img>& dog, int Col, int intvl, int r, int c, float xi, float xr, float xc) {
+    float dD[3];
+    deriv_3d(dog, Col, intvl, r, c, dD);
+    const float t = dD[0] * xc + dD[1] * xr + dD[2] * xi;
+    return dog[intvl][r * Col + c] + t * 0.5f;
+}
+
+// matrix.hpp:140-196.  Returns false where the reference returns nullptr.  One
+// defined behaviour is added: a step whose offsets are not finite or exceed 1e9
+// (singular Hessian) rejects the point; the reference converts such a value to
+// int, which is undefined.
+bool interp_extremum(const std::vector<Img>& dog, int COL, int ROW, int& intvl, int& r, int& c, int intvl_Len,
+                     double contr_thr, float sub[3]) {
+    float xi = 0.0, xr = 0.0, xc = 0.0;
+    int i = 0;
+    while (i < kMaxInterpSteps) {
+        interp_step(dog, COL, intvl, r, c, xi, xr, xc);
+        if (!(std::fabs(xi) < 1e9f && std::fabs(xr) < 1e9f && std::fabs(xc) < 1e9f)) return false;
+        if (std::fabs(xi) < 0.5 && std::fabs(xr) < 0.5 && std::fabs(xc) < 0.5) break;
+        c += (int)std::round(xc);
+        r += (int)std::round(xr);
+        intvl += (int)std::round(xi);
+        if (intvl < 1 || intvl > intvl_Len || c < kImgBorder || c >= COL - kImgBorder || r < kImgBorder ||
+            r >= ROW - kImgBorder)
+            return false;
+        i++;
+    }
+    if (i >= kMaxInterpSteps) return false;
+    const float contr = interp_contr(dog, COL, intvl, r, c, xi, xr, xc);
+    if (std::fabs(contr) < (float)(contr_thr)) return false;
+    sub[0] = xc;
+    sub[1] = xr;
+    sub[2] = xi;
+    return true;
+}
+
 struct Octave {
     int W = 0, H = 0;
     std::vector<Img> gau, dog;
@@ -388,7 +490,13 @@ void build_octave(Octave& oc, const Img& gray, size_t w, size_t h, size_t ph, si
 }
 
 // Sift/Sift.cpp:169-202 for one octave: scan, orientation, descriptors.
-void detect_octave(std::vector<Feat>& feats, const Octave& oc, size_t ph, size_t pyWidth, int describe) {
+// subpixel != 0 inserts the refinement where the reference has it commented out
+// (Sift.cpp:186-191), called as its signature intends (COL = width, r = j, c = i):
+// a rejected point is dropped, an accepted one is moved to the refined (layer,
+// row, column) and keeps the offsets; the orientation window must still fit the
+// image at the new place (the scan bounds of the new layer), else it is dropped.
+void detect_octave(std::vector<Feat>& feats, const Octave& oc, size_t ph, size_t pyWidth, int describe,
+                   int subpixel = 0, double contr_thr = 0.05) {
     float curr_size = 2.f, coef = 1.f;
     for (size_t k = 0; k < ph; k++) { curr_size /= 2.f; coef *= 2.f; }
     const size_t W = oc.W, H = oc.H;
@@ -404,7 +512,20 @@ void detect_octave(std::vector<Feat>& feats, const Octave& oc, size_t ph, size_t
                     const Img& cur = oc.dog[intvl_idx];
                     const float currSigma = kGauSigma * powf(std::sqrt(2.0), intvl_idx) * coef;
                     if (harris_corner(cur, W, j, i, r)) {
-                        histogram_ms(feats, cur, W, curr_size, intvl_idx, currSigma, j, i, r);
+                        if (!subpixel) {
+                            histogram_ms(feats, cur, W, curr_size, intvl_idx, currSigma, j, i, r);
+                            continue;
+                        }
+                        int li = (int)intvl_idx, rr = (int)j, cc = (int)i;
+                        float sub[3];
+                        if (!interp_extremum(oc.dog, (int)W, (int)H, li, rr, cc, (int)pyWidth - 3, contr_thr, sub))
+                            continue;
+                        const size_t r2 = curr_size * 3. * 1.5 * (li + 1);
+                        if (H < 2 * r2 + 3 || W < 2 * r2 + 3 || (size_t)rr < r2 + 1 || (size_t)rr >= H - r2 - 1 ||
+                            (size_t)cc < r2 + 1 || (size_t)cc >= W - r2 - 1)
+                            continue;
+                        const float sigma2 = kGauSigma * powf(std::sqrt(2.0), (size_t)li) * coef;
+                        histogram_ms(feats, oc.dog[li], W, curr_size, li, sigma2, rr, cc, r2, sub);
                     }
                 }
             }
@@ -492,8 +613,9 @@ void orc_octave_levels(const float* gray, int w, int h, int octave, int intvls, 
 // Sift::pyramid (Sift/Sift.cpp:140-225).  octaves==0 -> reference's own count.
 // hist_out (optional): n x 128 clamped raw histograms.  Returns feature count
 // (the full count even when it exceeds cap; only cap entries are written).
-int orc_extract(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,
-                float* hist_out, int describe) {
+// sub_out (optional): n x 3 sub-pixel offsets (xc, xr, xi).
+int orc_extract_ex(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,
+                   float* hist_out, int describe, int subpixel, double contr_thr, float* sub_out) {
     Img g(gray, gray + (size_t)w * h);
     const size_t pyWidth = intvls + 3;
     size_t octvs = octaves > 0 ? (size_t)octaves : pyramid_octaves(w, h);
@@ -502,7 +624,7 @@ int orc_extract(const float* gray, int w, int h, int octaves, int intvls, orc_fe
         Octave oc;
         build_octave(oc, g, w, h, ph, pyWidth);
         if (oc.W < 2 || oc.H < 2) break;
-        detect_octave(feats, oc, ph, pyWidth, describe);
+        detect_octave(feats, oc, ph, pyWidth, describe, subpixel, contr_thr);
     }
     const int n = (int)feats.size();
     for (int k = 0; k < n && k < cap; k++) {
@@ -512,8 +634,14 @@ int orc_extract(const float* gray, int w, int h, int octaves, int intvls, orc_fe
         o.mm = f.mm; o.sita = f.sita;
         for (int i = 0; i < 128; i++) o.descr[i] = (uint8_t)f.descr[i];
         if (hist_out) std::memcpy(hist_out + (size_t)k * 128, f.hist, 128 * 4);
+        if (sub_out) std::memcpy(sub_out + (size_t)k * 3, f.sub, 3 * 4);
     }
     return n;
+}
+
+int orc_extract(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,
+                float* hist_out, int describe) {
+    return orc_extract_ex(gray, w, h, octaves, intvls, out, cap, hist_out, describe, 0, 0.05, nullptr);
 }
 
 // Sift/Sift.cpp:537-567  forceMatchFeat on float descriptors (d == 128):

@@ -101,6 +101,7 @@ def load_library() -> C.CDLL:
         "sift_hip_extract_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, P, vp, C.c_int, ip, vp]),
         "sift_hip_extract_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip]),
         "sift_hip_extract_batch_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip]),
+        "sift_hip_last_offsets": (C.c_int, [vp, fp, C.c_int]),
         "sift_hip_gau_matrix": (C.c_int, [C.c_float, C.c_int, fp, C.c_int]),
         "sift_hip_gau_blur": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]),
         "sift_hip_first": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
@@ -201,6 +202,14 @@ class SiftHip:
                 continue
             self._check(rc)
             return out[: n.value], (hist[: n.value] if want_hist else None)
+
+    def last_offsets(self, n: int) -> np.ndarray:
+        """(xc, xr, xi) of the n features the last extract returned (subpixel = 1)."""
+        out = np.zeros((max(n, 1), 3), np.float32)
+        got = self.lib.sift_hip_last_offsets(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+        if got < 0:
+            self._check(got)
+        return out[:got]
 
     def extract_dev(self, d_gray, w: int, h: int, params: SiftParams | None, out: np.ndarray, hist=None) -> int:
         """d_gray: device pointer (int) or torch CUDA tensor; out: preallocated FEAT_DTYPE array."""

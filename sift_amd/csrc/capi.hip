@@ -288,6 +288,10 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         if ((rc = ensure(ctx, ws->counters, CNT_SLOTS * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ws->feat, (size_t)std::max(1, feat_cap) * sizeof(sift_hip_feat)))) return rc;
         if (want_hist && (rc = ensure(ctx, ws->hist, (size_t)std::max(1, feat_cap) * 128 * sizeof(float)))) return rc;
+        if (prm.subpixel) {
+            if ((rc = ensure(ctx, ws->cand_sub, (size_t)cand_cap * sizeof(float4)))) return rc;
+            if ((rc = ensure(ctx, ws->feat_sub, (size_t)std::max(1, feat_cap) * 3 * sizeof(float)))) return rc;
+        }
     }
     if (!hip_ok(ctx, hipMemsetAsync(ctx->gcounters.p, 0, G_SLOTS * sizeof(int), ctx->stream), "reset counters"))
         return SIFT_HIP_ERR_HIP;
@@ -315,8 +319,9 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         if (!rc) {
             const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
             launch_detect(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap);
+            if (prm.subpixel) launch_refine(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, prm.contr_thr);
             launch_orient(ctx, ws, PX, oc.W, d_lc, (const float*)ctx->table.p);
-            launch_emit(ctx, ws, oi, oc.curr_size, d_lc, feat_cap);
+            launch_emit(ctx, ws, oi, oc.curr_size, d_lc, feat_cap, prm.subpixel != 0);
             int max_window = 1;
             for (int li = 0; li < prm.intvls; li++) {
                 // descriptor radius of Sift.cpp:357 for this layer's integer-truncated sigma
@@ -347,6 +352,13 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
     *cand_overflow = ctx->h_counters[G_CAND_OVERFLOW];
     if (*cand_overflow) return SIFT_HIP_OK;
     const int noct = (int)ctx->plan.oct.size();
+    const bool with_sub = ctx->plan.prm.subpixel != 0;
+    ctx->h_sub.clear();
+    if (with_sub) {
+        long long want = 0;
+        for (int oi = 0; oi < noct; oi++) want += ctx->h_counters[G_OCT_FEATS + oi];
+        ctx->h_sub.resize((size_t)std::min<long long>(want, cap) * 3);
+    }
     long long total = 0;
     int copied = 0;
     for (int oi = 0; oi < noct; oi++) {
@@ -359,6 +371,10 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
             if (hist && !hip_ok(ctx, hipMemcpyAsync(hist + (size_t)copied * 128, ctx->lanes[oi].hist.p,
                                                     (size_t)m * 128 * sizeof(float), hipMemcpyDeviceToHost,
                                                     ctx->stream), "read histograms"))
+                return SIFT_HIP_ERR_HIP;
+            if (with_sub && !hip_ok(ctx, hipMemcpyAsync(ctx->h_sub.data() + (size_t)copied * 3, ctx->lanes[oi].feat_sub.p,
+                                                        (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost,
+                                                        ctx->stream), "read offsets"))
                 return SIFT_HIP_ERR_HIP;
             copied += m;
         }
@@ -375,6 +391,7 @@ static int extract_dev_impl(sift_hip_ctx* ctx, const float* d_gray, int w, int h
     if (params) prm = *params; else sift_hip_default_params(&prm);
     if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || prm.octaves > 24 || !(prm.sigma0 > 0.f))
         return SIFT_HIP_ERR_ARG;
+    if (prm.subpixel != 0 && prm.subpixel != 1) return SIFT_HIP_ERR_ARG;
     // octave 0 is the image doubled in both directions; the kernels index one level with 32 bits
     if ((long long)w * h * 4 >= (1ll << 31)) return SIFT_HIP_ERR_LIMIT;
     int cand_cap = std::max(ctx->cand_cap, std::max(cap, 1 << 16));
@@ -436,7 +453,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     for (OctWs& ws : ctx->lanes) {
         if (ws.own_stream && ws.stream) hipStreamSynchronize(ws.stream);
         DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
-                        &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist};
+                        &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist, &ws.cand_sub, &ws.feat_sub};
         for (DevBuf* b : wb)
             if (b->p) hipFree(b->p);
         if (ws.ev_emit) hipEventDestroy(ws.ev_emit);
@@ -694,6 +711,13 @@ int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t
     if (d2) hipMemcpyAsync(d2, ctx->d2.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "match")) return SIFT_HIP_ERR_HIP;
     return check_async(ctx, "match");
+}
+
+int sift_hip_last_offsets(sift_hip_ctx* ctx, float* xyz, int cap) {
+    if (!ctx || cap < 0 || (cap > 0 && !xyz)) return SIFT_HIP_ERR_ARG;
+    const int n = (int)std::min<size_t>(ctx->h_sub.size() / 3, (size_t)cap);
+    if (n > 0) std::memcpy(xyz, ctx->h_sub.data(), (size_t)n * 3 * sizeof(float));
+    return n;
 }
 
 int sift_hip_profile(sift_hip_ctx* ctx, int enable) {

@@ -231,6 +231,103 @@ __global__ __launch_bounds__(64) void expand_rows_kernel(const unsigned long lon
     }
 }
 
+// ---- interp_extremum, matrix.hpp:140-196 (optional stage) -------------------------
+// Lowe's sub-pixel refinement, one lane per candidate, expression by expression as
+// the (never compiled) reference header states it: x = -H^-1 * dD from central
+// differences of the DoG stack (deriv_3D :12-33, hessian_3D :34-67, the closed-form
+// inverse :68-86), at most 5 steps, border 5, contrast test on the interpolated
+// value.  The reference's only call (Sift.cpp:187) is commented out and mixes up
+// its row/column arguments; here it runs as its signature intends.  A rejected
+// candidate gets layer 0, an accepted one moves to the refined (layer, row,
+// column) and must still leave room for that layer's orientation window (the
+// scan bounds of Sift.cpp:178-179).  Offsets that are not finite or exceed 1e9
+// (singular Hessian) reject the point; the reference's int conversion of such a
+// value is undefined.
+__global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
+                                                     int intvls, const LayerConsts* __restrict__ lc,
+                                                     float contr_thr, Cand* __restrict__ cand,
+                                                     float4* __restrict__ cand_sub,
+                                                     const int* __restrict__ counters) {
+    const int ncand = counters[CNT_NCAND];
+    for (int ci = blockIdx.x * 256 + threadIdx.x; ci < ncand; ci += gridDim.x * 256) {
+        const Cand cd = cand[ci];
+        int li = cd.layer, r = cd.y, c = cd.x;
+        // dog[l] = gau[l] - gau[l+1]
+        auto D = [&](int l, int rr, int cc) -> float {
+            const size_t p = (size_t)l * PX + (size_t)rr * W + cc;
+            return gau[p] - gau[p + PX];
+        };
+        float xi = 0.f, xr = 0.f, xc = 0.f;
+        float dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
+        bool ok = true;
+        int i = 0;
+        while (i < 5) {
+            const float v = D(li, r, c);
+            const float xp = D(li, r, c + 1), xm = D(li, r, c - 1);
+            const float yp = D(li, r + 1, c), ym = D(li, r - 1, c);
+            const float sp = D(li + 1, r, c), sm = D(li - 1, r, c);
+            dD0 = (xp - xm) / 2.f;
+            dD1 = (yp - ym) / 2.f;
+            dD2 = (sp - sm) / 2.f;
+            const float dxx = (xp + xm - 2.f * v);
+            const float dyy = (yp + ym - 2.f * v);
+            const float dss = (sp + sm - 2.f * v);
+            const float dxy = (D(li, r + 1, c + 1) - D(li, r + 1, c - 1) - D(li, r - 1, c + 1) + D(li, r - 1, c - 1)) / 4.f;
+            const float dxs = (D(li + 1, r, c + 1) - D(li + 1, r, c - 1) - D(li - 1, r, c + 1) + D(li - 1, r, c - 1)) / 4.f;
+            const float dys = (D(li + 1, r + 1, c) - D(li + 1, r - 1, c) - D(li - 1, r + 1, c) + D(li - 1, r - 1, c)) / 4.f;
+            // H = [dxx dxy dxs; dxy dyy dys; dxs dys dss], inverse by cofactors
+            const float v0 = dxx, v1 = dxy, v2 = dxs, v3 = dxy, v4 = dyy, v5 = dys, v6 = dxs, v7 = dys, v8 = dss;
+            float det = v0 * (v4 * v8 - v5 * v7);
+            det -= v3 * (v1 * v8 - v2 * v7);
+            det += v6 * (v1 * v5 - v2 * v4);
+            const float m0 = (v4 * v8 - v5 * v7) / det;
+            const float m1 = -(v1 * v8 - v2 * v7) / det;
+            const float m2 = (v1 * v5 - v2 * v4) / det;
+            const float m3 = -(v3 * v8 - v5 * v6) / det;
+            const float m4 = (v0 * v8 - v2 * v6) / det;
+            const float m5 = -(v0 * v5 - v2 * v3) / det;
+            const float m6 = (v3 * v7 - v4 * v6) / det;
+            const float m7 = -(v0 * v7 - v1 * v6) / det;
+            const float m8 = (v0 * v4 - v1 * v3) / det;
+            xc = (m0 * dD0 + m1 * dD1 + m2 * dD2) * -1.f;
+            xr = (m3 * dD0 + m4 * dD1 + m5 * dD2) * -1.f;
+            xi = (m6 * dD0 + m7 * dD1 + m8 * dD2) * -1.f;
+            if (!(fabsf(xi) < 1e9f && fabsf(xr) < 1e9f && fabsf(xc) < 1e9f)) {
+                ok = false;
+                break;
+            }
+            if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+            c += (int)roundf(xc);
+            r += (int)roundf(xr);
+            li += (int)roundf(xi);
+            if (li < 1 || li > intvls || c < 5 || c >= W - 5 || r < 5 || r >= H - 5) {
+                ok = false;
+                break;
+            }
+            i++;
+        }
+        if (ok && i >= 5) ok = false;
+        float contr = 0.f;
+        if (ok) {
+            // interp_contr, matrix.hpp:113-124 (the derivative at the final point is the last one computed)
+            const float t = dD0 * xc + dD1 * xr + dD2 * xi;
+            contr = D(li, r, c) + t * 0.5f;
+            if (fabsf(contr) < contr_thr) ok = false;
+        }
+        if (ok) {
+            const int rad = lc[li - 1].radius;
+            ok = (H >= 2 * rad + 3) && (W >= 2 * rad + 3) && r >= rad + 1 && r < H - rad - 1 && c >= rad + 1 &&
+                 c < W - rad - 1;
+        }
+        Cand o;
+        o.x = c;
+        o.y = r;
+        o.layer = ok ? li : 0;
+        cand[ci] = o;
+        cand_sub[ci] = make_float4(xc, xr, xi, contr);
+    }
+}
+
 // ---- fastAtan2f, Imgraw.cpp:29-52 (degrees) ------------------------------------
 __device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
     const float k = (float)(180 / 3.14159265358979323846);
@@ -298,6 +395,10 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
     const unsigned half_shift = (lane & 1) * 16;
     for (int ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
         const Cand cd = cand[ci];
+        if (cd.layer == 0) {  // rejected by the sub-pixel stage (wave-uniform)
+            if (lane == 0) cmask[ci] = 0ull;
+            continue;
+        }
         const LayerConsts L = lc[cd.layer - 1];
         const int r = L.radius;
         const int n = 2 * r + 1;
@@ -456,10 +557,13 @@ __global__ __launch_bounds__(256) void emit_kernel(const Cand* __restrict__ cand
                                                    const float* __restrict__ cmm, const int* __restrict__ cand_off,
                                                    const LayerConsts* __restrict__ lc, float curr_size,
                                                    sift_hip_feat* __restrict__ feat, int feat_cap,
-                                                   const int* __restrict__ counters) {
+                                                   const int* __restrict__ counters,
+                                                   const float4* __restrict__ cand_sub,
+                                                   float* __restrict__ feat_sub) {
     const int ncand = counters[CNT_NCAND];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
         unsigned long long m = cmask[i];
+        if (!m) continue;
         const Cand cd = cand[i];
         const LayerConsts L = lc[cd.layer - 1];
         int pos = cand_off[i];
@@ -475,6 +579,12 @@ __global__ __launch_bounds__(256) void emit_kernel(const Cand* __restrict__ cand
                 f->y = cd.y;
                 f->mm = cmm[(size_t)i * 36 + bin];
                 f->sita = bin * 10;
+                if (feat_sub) {
+                    const float4 o = cand_sub[i];
+                    feat_sub[(size_t)pos * 3 + 0] = o.x;
+                    feat_sub[(size_t)pos * 3 + 1] = o.y;
+                    feat_sub[(size_t)pos * 3 + 2] = o.z;
+                }
             }
             pos++;
         }
@@ -504,6 +614,13 @@ void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
     }
 }
 
+void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
+                   float contr_thr) {
+    ProfScope ps(ctx, SIFT_HIP_K_COMPACT, ws.stream);
+    hipLaunchKernelGGL(refine_kernel, dim3(256), dim3(256), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H, intvls,
+                       d_lc, contr_thr, (Cand*)ws.cand.p, (float4*)ws.cand_sub.p, (const int*)ws.counters.p);
+}
+
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table) {
     ProfScope ps(ctx, SIFT_HIP_K_ORIENT, ws.stream);
     hipLaunchKernelGGL(orient_kernel, dim3(256 * 12), dim3(64), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, d_lc,
@@ -511,7 +628,8 @@ void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerCo
                        (float*)ws.cand_mm.p);
 }
 
-void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap) {
+void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap,
+                 bool with_sub) {
     ProfScope ps(ctx, SIFT_HIP_K_EMIT, ws.stream);
     hipLaunchKernelGGL(emit_scan_kernel, dim3(1), dim3(1024), 0, ws.stream,
                        (const unsigned long long*)ws.cand_mask.p, (int*)ws.cand_off.p, (int*)ws.counters.p,
@@ -519,7 +637,8 @@ void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, cons
     hipLaunchKernelGGL(emit_kernel, dim3(128), dim3(256), 0, ws.stream, (const Cand*)ws.cand.p,
                        (const unsigned long long*)ws.cand_mask.p, (const float*)ws.cand_mm.p,
                        (const int*)ws.cand_off.p, d_lc, curr_size, (sift_hip_feat*)ws.feat.p, feat_cap,
-                       (const int*)ws.counters.p);
+                       (const int*)ws.counters.p, (const float4*)ws.cand_sub.p,
+                       with_sub ? (float*)ws.feat_sub.p : nullptr);
 }
 
 }  // namespace sifthip

@@ -44,6 +44,7 @@ struct OctWs {
     bool own_stream = false;
     hipEvent_t ev_emit = nullptr, ev_done = nullptr;
     DevBuf base, tmp, gau_all, masks, row_cnt, row_off, cand, cand_mask, cand_mm, cand_off, counters, feat, hist;
+    DevBuf cand_sub, feat_sub;  // sub-pixel offsets per candidate (float4) / per feature (3 floats)
 };
 
 struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-183)
@@ -83,6 +84,7 @@ struct sift_hip_ctx {
     int cand_cap = 0;
     // pinned host staging
     int32_t* h_counters = nullptr;
+    std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
 
     // profiling
@@ -133,8 +135,11 @@ struct LayerConsts {  // per DoG layer 1..intvls of one octave
 // (DoG values are recomputed from adjacent levels, never stored).
 void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
                    float thr, int cand_cap);
+void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
+                   float contr_thr);
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table);
-void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap);
+void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap,
+                 bool with_sub);
 // descriptor.hip; max_window: sample count (2R+1)^2 of the octave's largest descriptor window
 void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const float* d_cs, int feat_cap,
                   float* d_hist, int max_window);

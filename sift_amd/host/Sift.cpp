@@ -171,6 +171,13 @@ void Sift::pyramid() {
         check(ctx, rc, "sift_hip_extract");
         break;
     }
+    // refined positions (matrix.hpp:188-189); without refinement img_pt stays zero as in the reference
+    std::vector<float> sub;
+    if (prm.subpixel && n > 0) {
+        sub.resize((size_t)n * 3);
+        const int got = sift_hip_last_offsets(ctx, sub.data(), n);
+        if (got != n) check(ctx, got < 0 ? got : SIFT_HIP_ERR_HIP, "sift_hip_last_offsets");
+    }
     // the reference copies its linked list into new Feature[feaNum] (Sift.cpp:207-224)
     Feature* arr = new Feature[n > 0 ? n : 1];
     for (int i = 0; i < n; i++) {
@@ -185,6 +192,10 @@ void Sift::pyramid() {
         f.sita = s.sita;
         for (int k = 0; k < 128; k++) f.descr[k] = (float)s.descr[k];
         f.d = 128;
+        if (!sub.empty()) {
+            f.img_pt.x = ((float)s.x + sub[(size_t)i * 3 + 0]) / s.size;
+            f.img_pt.y = ((float)s.y + sub[(size_t)i * 3 + 1]) / s.size;
+        }
     }
     delete[] FeatStart;
     FeatStart = arr;

@@ -71,8 +71,19 @@ int main(int argc, char** argv) {
         // the image-op mirrors: blur into the same vector must throw file_same
         bool threw = false;
         try { Gaus::GauBlur(img1.raw_img, img1.raw_img, w, h, 1.6f); } catch (const file_same&) { threw = true; }
-        printf("{\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s}\n", fea1.feaNum, fea2.feaNum, matched,
-               threw ? "true" : "false");
+        // optional sub-pixel stage: img_pt carries the refined source-image position
+        sift_amd::options().subpixel = 1;
+        Sift fea3(img1);
+        fea3.pyramid();
+        sift_amd::options().subpixel = 0;
+        double sx = 0.0, sy = 0.0;
+        for (size_t i = 0; i < fea3.feaNum; i++) {
+            sx += fea3.FeatStart[i].img_pt.x;
+            sy += fea3.FeatStart[i].img_pt.y;
+        }
+        printf("{\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
+               "\"sub_sum_y\": %.6f}\n",
+               fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy);
     } catch (const std::exception& e) {
         fprintf(stderr, "selftest failed: %s\n", e.what());
         return 1;

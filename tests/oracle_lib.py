@@ -45,6 +45,8 @@ class Oracle:
         o.orc_convert_gray.argtypes = [vp, C.c_int, vp]
         o.orc_octave_levels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, ip, ip]
         o.orc_extract.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
+        o.orc_extract_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int,
+                                     C.c_double, vp]
         o.orc_force_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp]
         o.orc_match_u8.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]
         self.o = o
@@ -95,16 +97,23 @@ class Oracle:
         return gau, dog
 
     def extract(self, gray, octaves=0, intvls=3, cap=1 << 16, describe=True):
+        f, h, _ = self.extract_ex(gray, octaves, intvls, cap, describe)
+        return f, h
+
+    def extract_ex(self, gray, octaves=0, intvls=3, cap=1 << 16, describe=True, subpixel=0, contr_thr=0.05):
+        """-> (features, clamped histograms, sub-pixel offsets n x 3 = (xc, xr, xi))."""
         gray = np.ascontiguousarray(gray, np.float32)
         h, w = gray.shape
         while True:
             out = np.zeros(cap, FEAT_DTYPE)
             hist = np.zeros((cap, 128), np.float32)
-            n = self.o.orc_extract(_p(gray), w, h, octaves, intvls, _p(out), cap, _p(hist), int(describe))
+            sub = np.zeros((cap, 3), np.float32)
+            n = self.o.orc_extract_ex(_p(gray), w, h, octaves, intvls, _p(out), cap, _p(hist), int(describe),
+                                      int(subpixel), C.c_double(contr_thr), _p(sub))
             if n > cap:
                 cap = n
                 continue
-            return out[:n], hist[:n]
+            return out[:n], hist[:n], sub[:n]
 
     def force_match(self, q, r, th):
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 128)

@@ -48,6 +48,13 @@ def test_cpp_classes_equal_c_abi_and_oracle(tmp_path, sift, oracle):
     bo, _, _ = oracle.match_u8(fb["descr"], fa["descr"], 0.5, 0)
     assert np.array_equal(m, bo)
     assert info["matched"] == int((bo >= 0).sum()) > 20
+    # options().subpixel = 1: Feature::img_pt = (x + xc, y + xr) / size (matrix.hpp:188-189)
+    fs, _ = sift.extract(a, sift_amd.SiftParams(subpixel=1))
+    sub = sift.last_offsets(len(fs))
+    assert info["n_sub"] == len(fs) > 5
+    px = ((fs["x"] + sub[:, 0]) / fs["size"]).astype(np.float32).astype(np.float64)
+    py = ((fs["y"] + sub[:, 1]) / fs["size"]).astype(np.float32).astype(np.float64)
+    assert abs(info["sub_sum_x"] - px.sum()) < 1e-2 and abs(info["sub_sum_y"] - py.sum()) < 1e-2
 
 
 def test_cpp_classes_rgb_input(tmp_path, oracle):

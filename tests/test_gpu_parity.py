@@ -249,3 +249,33 @@ def test_gau_blur_explicit_length(sift, oracle):
         return np.moveaxis(acc.astype(np.float32), 0, axis)
     want = conv(conv(img, 1), 0)
     assert np.array_equal(bits(got), bits(want))
+
+
+# ---- optional sub-pixel stage (matrix.hpp:140-196, dead code in the reference) --------
+@pytest.mark.parametrize("w,h,seed,thr", [(256, 192, 1, 0.05), (640, 480, 1, 0.05), (320, 200, 5, 0.0)])
+def test_subpixel_extract_matches_oracle(sift, oracle, w, h, seed, thr):
+    img = sift_amd.blob_image(w, h, seed=seed)
+    prm = SiftParams(subpixel=1, contr_thr=thr)
+    f, hist = sift.extract(img, prm, want_hist=True)
+    sub = sift.last_offsets(len(f))
+    fo, ho, so = oracle.extract_ex(img, subpixel=1, contr_thr=thr)
+    assert len(fo) > 20
+    check_features(f, hist, fo, ho)
+    assert np.array_equal(bits(sub), bits(so))
+    assert (np.abs(sub) < 0.5).all()
+    # refinement only removes or moves keypoints: never more than without it
+    f0, _ = sift.extract(img)
+    assert len(f) <= len(f0)
+    assert len(sift.last_offsets(len(f0))) == 0  # the last call ran without refinement
+
+
+def test_subpixel_flag_is_validated(sift):
+    import ctypes as C
+
+    img = sift_amd.blob_image(64, 64, seed=1)
+    out = np.zeros(16, sift_amd.FEAT_DTYPE)
+    n = C.c_int(0)
+    prm = SiftParams(subpixel=2)._c()
+    rc = sift.lib.sift_hip_extract(sift.h, C.c_void_p(img.ctypes.data), 64, 64, 1, C.byref(prm),
+                                   C.c_void_p(out.ctypes.data), 16, C.byref(n), None)
+    assert rc == sift_amd.capi.ERR_ARG
