@@ -130,7 +130,9 @@ def main():
         alg_stage = sum(px) * stage_bytes_per_px
         traffic = None
         traffic_note = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))  # newest round/letter last
+        tpath = tfiles[-1] if tfiles else ""
         kname = {"blur_col": "blur_col_kernel<double, 8>", "blur_row": "blur_row_kernel<double, 8>"}[dom] \
             if args.blur_mode == 0 else None
         if kname and os.path.exists(tpath) and (W, H, args.octaves) == (3840, 2160, 4):
@@ -139,7 +141,7 @@ def main():
             if kk:
                 traffic = round((kk["read"] + kk["write"]) / kk["launches_per_frame"])
                 traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this workload, " \
-                               "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, per launch; profiles/r01_traffic.json"
+                               "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, per launch; profiles/" + os.path.basename(tpath)
         # VALU floor of the exact blur: 4.86 ns per wave-level (v_mul_f32, v_cvt_f64_f32, v_add_f64)
         # triple per SIMD (tools/microbench_valu.hip), 1024 SIMDs
         taps = 0
@@ -176,6 +178,27 @@ def main():
                     "which makes the blur fp64-VALU-bound (v_mul_f32 + v_cvt_f64_f32 + v_add_f64 per tap), not "
                     "HBM-bound; frac_of_valu_floor is the efficiency against that bound",
         }
+
+    # ---- side measurements (rank 0, outside the timed region; none of them is `value`) -------
+    extras = None
+    if rank == 0:
+        extras = {}
+        # the same frame handed over as a host buffer: upload over PCIe included
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.extract(frame.reshape(H, W), prm, cap=cap)
+        extras["host_buffer_ms_per_frame"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        if args.blur_mode == 0:
+            # fp32-FMA blur: not the reference's arithmetic (a fraction of a percent of keypoints change)
+            fast = SiftParams(octaves=args.octaves, blur_mode=1)
+            nfast = ctx.extract_dev(d_frame, W, H, fast, out)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                nfast = ctx.extract_dev(d_frame, W, H, fast, out)
+            extras["blur_mode_1_ms_per_frame"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+            extras["blur_mode_1_features"] = int(nfast)
+            ctx.extract_dev(d_frame, W, H, prm, out)  # back to the exact plan
 
     # ---- match leg ---------------------------------------------------------------------
     match = None
@@ -228,7 +251,7 @@ def main():
         from tests.oracle_lib import Oracle
 
         orc = Oracle()
-        cw, ch = min(W, 1280), min(H, 720)
+        cw, ch = min(W, 2560), min(H, 1440)
         crop = np.ascontiguousarray(frame[:ch, :cw])
         t0 = time.perf_counter()
         fo, _ = orc.extract(crop, octaves=args.octaves)
@@ -243,12 +266,12 @@ def main():
                       "scaled by pixel count to a full %dx%d frame" % (cw, ch, args.octaves, ct, len(fo), W, H),
         }
         if args.match_n > 0:
-            qs, rs = sift_amd.planted_descriptors(2048, 8192)
+            qs, rs = sift_amd.planted_descriptors(4096, 32768)
             t0 = time.perf_counter()
             orc.match_u8(qs, rs, 0.5, 0)
             mt = time.perf_counter() - t0
-            cpu["match_gpairs_per_s"] = round(2048 * 8192 / mt / 1e9, 5)
-            cpu["match_sample"] = "oracle exact NN, 2048 x 8192 descriptors, 1 thread, %.2f s" % mt
+            cpu["match_gpairs_per_s"] = round(4096 * 32768 / mt / 1e9, 5)
+            cpu["match_sample"] = "oracle exact NN, 4096 x 32768 descriptors, 1 thread, %.2f s" % mt
 
     if rank == 0:
         line = {
@@ -271,6 +294,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "match": match,
+            "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
