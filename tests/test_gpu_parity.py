@@ -279,3 +279,38 @@ def test_subpixel_flag_is_validated(sift):
     rc = sift.lib.sift_hip_extract(sift.h, C.c_void_p(img.ctypes.data), 64, 64, 1, C.byref(prm),
                                    C.c_void_p(out.ctypes.data), 16, C.byref(n), None)
     assert rc == sift_amd.capi.ERR_ARG
+
+
+# ---- other scale-space shapes and ragged sizes ------------------------------------------
+@pytest.mark.parametrize("intvls", [1, 2, 4, 5])
+def test_extract_other_interval_counts(sift, oracle, intvls):
+    # Sift(ImgRaw, intvls) (Sift.hpp:99): pyWidth = intvls + 3 levels per octave
+    img = sift_amd.blob_image(200, 168, seed=6)
+    f, hist = sift.extract(img, SiftParams(intvls=intvls), want_hist=True)
+    fo, ho = oracle.extract(img, intvls=intvls)
+    assert len(fo) > 10
+    check_features(f, hist, fo, ho)
+
+
+@pytest.mark.parametrize("w,h", [(101, 99), (150, 77), (77, 150), (131, 67), (193, 65), (33, 200), (64, 64), (2, 2), (7, 5)])
+def test_extract_ragged_and_tiny_sizes(sift, oracle, w, h):
+    # widths that are not multiples of the 64-pixel tiles / 8-pixel thread runs, and
+    # images smaller than every scan window (no features, no fault)
+    img = sift_amd.blob_image(w, h, seed=10)
+    f, hist = sift.extract(img, want_hist=True)
+    fo, ho = oracle.extract(img)
+    assert len(f) == len(fo)
+    if min(w, h) > 64:
+        assert len(fo) > 5
+    if len(fo):
+        check_features(f, hist, fo, ho)
+
+
+def test_extract_subpixel_with_other_interval_count(sift, oracle):
+    img = sift_amd.blob_image(240, 200, seed=7)
+    prm = SiftParams(intvls=4, subpixel=1, contr_thr=0.0)
+    f, hist = sift.extract(img, prm, want_hist=True)
+    fo, ho, so = oracle.extract_ex(img, intvls=4, subpixel=1, contr_thr=0.0)
+    assert len(fo) > 10
+    check_features(f, hist, fo, ho)
+    assert np.array_equal(bits(sift.last_offsets(len(f))), bits(so))
