@@ -344,11 +344,13 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
 
 // Copies the counters back, then each octave's features (and histograms) to their
 // place in the caller's array: octave-major, as the reference appends them.
-static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow) {
+static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow,
+                          hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
     if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
-                                    ctx->stream), "read counters"))
+                                    st), "read counters"))
         return SIFT_HIP_ERR_HIP;
-    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "extract")) return SIFT_HIP_ERR_HIP;
+    if (!hip_ok(ctx, hipStreamSynchronize(st), "extract")) return SIFT_HIP_ERR_HIP;
     *cand_overflow = ctx->h_counters[G_CAND_OVERFLOW];
     if (*cand_overflow) return SIFT_HIP_OK;
     const int noct = (int)ctx->plan.oct.size();
@@ -366,38 +368,44 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
         const int m = std::max(0, std::min(cnt, cap - copied));  // the octave's buffer holds at most cap
         if (m > 0) {
             if (!hip_ok(ctx, hipMemcpyAsync(out + copied, ctx->lanes[oi].feat.p, (size_t)m * sizeof(sift_hip_feat),
-                                            hipMemcpyDeviceToHost, ctx->stream), "read features"))
+                                            hipMemcpyDeviceToHost, st), "read features"))
                 return SIFT_HIP_ERR_HIP;
             if (hist && !hip_ok(ctx, hipMemcpyAsync(hist + (size_t)copied * 128, ctx->lanes[oi].hist.p,
                                                     (size_t)m * 128 * sizeof(float), hipMemcpyDeviceToHost,
-                                                    ctx->stream), "read histograms"))
+                                                    st), "read histograms"))
                 return SIFT_HIP_ERR_HIP;
             if (with_sub && !hip_ok(ctx, hipMemcpyAsync(ctx->h_sub.data() + (size_t)copied * 3, ctx->lanes[oi].feat_sub.p,
                                                         (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost,
-                                                        ctx->stream), "read offsets"))
+                                                        st), "read offsets"))
                 return SIFT_HIP_ERR_HIP;
             copied += m;
         }
         total += cnt;
     }
     *n = (int)std::min<long long>(total, INT32_MAX);
-    if (copied > 0 && !hip_ok(ctx, hipStreamSynchronize(ctx->stream), "read features")) return SIFT_HIP_ERR_HIP;
+    if (copied > 0 && !hip_ok(ctx, hipStreamSynchronize(st), "read features")) return SIFT_HIP_ERR_HIP;
     return total > cap ? SIFT_HIP_ERR_NOSPC : SIFT_HIP_OK;
+}
+
+static int checked_params(const sift_hip_params* params, int w, int h, sift_hip_params* prm) {
+    if (params) *prm = *params; else sift_hip_default_params(prm);
+    if (prm->intvls < 1 || prm->intvls > 8 || prm->octaves < 0 || prm->octaves > 24 || !(prm->sigma0 > 0.f))
+        return SIFT_HIP_ERR_ARG;
+    if (prm->subpixel != 0 && prm->subpixel != 1) return SIFT_HIP_ERR_ARG;
+    // octave 0 is the image doubled in both directions; the kernels index one level with 32 bits
+    if ((long long)w * h * 4 >= (1ll << 31)) return SIFT_HIP_ERR_LIMIT;
+    return SIFT_HIP_OK;
 }
 
 static int extract_dev_impl(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params* params,
                             sift_hip_feat* out, int cap, int* n, float* hist) {
     sift_hip_params prm;
-    if (params) prm = *params; else sift_hip_default_params(&prm);
-    if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || prm.octaves > 24 || !(prm.sigma0 > 0.f))
-        return SIFT_HIP_ERR_ARG;
-    if (prm.subpixel != 0 && prm.subpixel != 1) return SIFT_HIP_ERR_ARG;
-    // octave 0 is the image doubled in both directions; the kernels index one level with 32 bits
-    if ((long long)w * h * 4 >= (1ll << 31)) return SIFT_HIP_ERR_LIMIT;
+    int rc = checked_params(params, w, h, &prm);
+    if (rc) return rc;
     int cand_cap = std::max(ctx->cand_cap, std::max(cap, 1 << 16));
     for (int attempt = 0; attempt < 4; attempt++) {
         ctx->cand_cap = cand_cap;
-        int rc = enqueue_extract(ctx, d_gray, w, h, prm, cap, cand_cap, hist != nullptr);
+        rc = enqueue_extract(ctx, d_gray, w, h, prm, cap, cand_cap, hist != nullptr);
         if (rc) return rc;
         int overflow = 0;
         rc = fetch_features(ctx, out, cap, n, hist, &overflow);
@@ -405,6 +413,86 @@ static int extract_dev_impl(sift_hip_ctx* ctx, const float* d_gray, int w, int h
         cand_cap = overflow + overflow / 4;  // the candidate table was too small: grow and redo
     }
     return SIFT_HIP_ERR_LIMIT;
+}
+
+// The two output sets (feature buffers + counters) trade places.
+static void swap_output_sets(sift_hip_ctx* ctx) {
+    std::swap(ctx->gcounters, ctx->gcounters_alt);
+    std::swap(ctx->h_counters, ctx->h_counters_alt);
+    for (OctWs& ws : ctx->lanes) {
+        std::swap(ws.feat, ws.feat_alt);
+        std::swap(ws.feat_sub, ws.feat_sub_alt);
+    }
+}
+
+// A batch of equal-sized frames, software-pipelined over the two output sets:
+// frame f's kernels are enqueued before frame f-1's counters and features are
+// copied back (on the copy stream), so the device never waits for the host
+// between frames.  frame_ptr(f) returns the device address of frame f after
+// ordering ctx->stream behind whatever produces it; enqueued(f) is called once
+// frame f's kernels are in the stream.  If a frame overflows the candidate table
+// the rest of the batch falls back to the one-frame-at-a-time path, which grows it;
+// reload(f) returns frame f's device address for that path (the pipelined uploads
+// may have reused its slot by then).
+template <typename FramePtr, typename Enqueued, typename Reload>
+static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Enqueued enqueued, Reload reload, int w, int h,
+                                   int nframes, const sift_hip_params* params, sift_hip_feat* out, int cap, int* n) {
+    sift_hip_params prm;
+    int rc = checked_params(params, w, h, &prm);
+    if (rc) return rc;
+    int worst = SIFT_HIP_OK;
+    auto plain_from = [&](int f0) -> int {
+        for (int f = f0; f < nframes; f++) {
+            n[f] = 0;
+            const float* d = reload(f);
+            if (!d) return SIFT_HIP_ERR_HIP;
+            int r = extract_dev_impl(ctx, d, w, h, params, out + (size_t)f * cap, cap, &n[f], nullptr);
+            if (r == SIFT_HIP_ERR_NOSPC) worst = r;
+            else if (r) return r;
+        }
+        return worst;
+    };
+    if (ctx->profiling || nframes < 2) return plain_from(0);
+    const int cand_cap = std::max(ctx->cand_cap, std::max(cap, 1 << 16));
+    ctx->cand_cap = cand_cap;
+    for (int f = 0; f < nframes; f++) {
+        n[f] = 0;
+        const float* d = frame_ptr(f);
+        swap_output_sets(ctx);  // frame f writes the set that frame f-2 has released
+        rc = enqueue_extract(ctx, d, w, h, prm, cap, cand_cap, false);
+        enqueued(f);
+        if (rc) {
+            hipStreamSynchronize(ctx->stream);
+            return rc;
+        }
+        hipEventRecord(ctx->ev_frame[f & 1], ctx->stream);
+        if (f >= 1) {
+            swap_output_sets(ctx);  // look at frame f-1's set
+            // The host waits for frame f-1 (frame f keeps the device busy meanwhile), then
+            // copies on the copy stream.  No device-side wait between streams here: with
+            // more streams in the process than hardware queues (4), a stream waiting for
+            // an event of a stream that shares its queue never wakes up.
+            if (!hip_ok(ctx, hipEventSynchronize(ctx->ev_frame[(f - 1) & 1]), "batch frame")) return SIFT_HIP_ERR_HIP;
+            int overflow = 0;
+            rc = fetch_features(ctx, out + (size_t)(f - 1) * cap, cap, &n[f - 1], nullptr, &overflow, ctx->copy_stream);
+            swap_output_sets(ctx);
+            if (overflow) {
+                hipStreamSynchronize(ctx->stream);
+                return plain_from(f - 1);
+            }
+            if (rc == SIFT_HIP_ERR_NOSPC) worst = rc;
+            else if (rc) {
+                hipStreamSynchronize(ctx->stream);
+                return rc;
+            }
+        }
+    }
+    int overflow = 0;
+    rc = fetch_features(ctx, out + (size_t)(nframes - 1) * cap, cap, &n[nframes - 1], nullptr, &overflow);
+    if (overflow) return plain_from(nframes - 1);
+    if (rc == SIFT_HIP_ERR_NOSPC) worst = rc;
+    else if (rc) return rc;
+    return worst;
 }
 
 static bool bad_ctx(sift_hip_ctx* ctx) {
@@ -437,7 +525,10 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->h_counters, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_frame[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_frame[1], hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counters, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_counters_alt, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         sift_hip_destroy(ctx);
         return SIFT_HIP_ERR_HIP;
     }
@@ -453,7 +544,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     for (OctWs& ws : ctx->lanes) {
         if (ws.own_stream && ws.stream) hipStreamSynchronize(ws.stream);
         DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
-                        &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist, &ws.cand_sub, &ws.feat_sub};
+                        &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist, &ws.cand_sub, &ws.feat_sub, &ws.feat_alt, &ws.feat_sub_alt};
         for (DevBuf* b : wb)
             if (b->p) hipFree(b->p);
         if (ws.ev_emit) hipEventDestroy(ws.ev_emit);
@@ -461,7 +552,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
         if (ws.own_stream && ws.stream) hipStreamDestroy(ws.stream);
     }
     DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->table, &ctx->layer_consts,
-                      &ctx->gcounters, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
+                      &ctx->gcounters, &ctx->gcounters_alt, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -469,6 +560,8 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     if (ctx->h_feat.p) hipHostFree(ctx->h_feat.p);
     if (ctx->h_hist.p) hipHostFree(ctx->h_hist.p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
+    if (ctx->h_counters_alt) hipHostFree(ctx->h_counters_alt);
+    for (hipEvent_t e : ctx->ev_frame) if (e) hipEventDestroy(e);
     for (auto& e : ctx->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->free_events) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -555,15 +648,10 @@ int sift_hip_extract_batch_dev(sift_hip_ctx* ctx, const float* d_frames, int w, 
                                const sift_hip_params* params, sift_hip_feat* out, int cap, int* n) {
     if (bad_ctx(ctx) || !d_frames || w < 2 || h < 2 || nframes < 0 || !n || cap < 0 || (cap > 0 && !out))
         return SIFT_HIP_ERR_ARG;
-    int worst = SIFT_HIP_OK;
-    for (int f = 0; f < nframes; f++) {
-        n[f] = 0;
-        int rc = extract_dev_impl(ctx, d_frames + (size_t)f * w * h, w, h, params, out + (size_t)f * cap, cap, &n[f],
-                                  nullptr);
-        if (rc == SIFT_HIP_ERR_NOSPC) worst = rc;
-        else if (rc) return rc;
-    }
-    return worst;
+    const size_t px = (size_t)w * h;
+    return extract_batch_pipelined(
+        ctx, [&](int f) { return d_frames + (size_t)f * px; }, [](int) {},
+        [&](int f) { return d_frames + (size_t)f * px; }, w, h, nframes, params, out, cap, n);
 }
 
 int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h, int nframes,
@@ -577,13 +665,12 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
     float* slot[2] = {(float*)ctx->in_img.p, (float*)ctx->frame2.p};
     hipEvent_t up[2], done[2];
     for (int i = 0; i < 2; i++) { hipEventCreateWithFlags(&up[i], hipEventDisableTiming); hipEventCreateWithFlags(&done[i], hipEventDisableTiming); }
-    int worst = SIFT_HIP_OK;
     // frame f+1 is uploaded on the copy stream while frame f's kernels run
     if (nframes > 0) {
         hipMemcpyAsync(slot[0], frames, px * 4, hipMemcpyHostToDevice, ctx->copy_stream);
         hipEventRecord(up[0], ctx->copy_stream);
     }
-    for (int f = 0; f < nframes && worst != SIFT_HIP_ERR_HIP; f++) {
+    auto frame_ptr = [&](int f) -> const float* {
         const int s = f & 1;
         if (f + 1 < nframes) {
             if (f >= 1) hipStreamWaitEvent(ctx->copy_stream, done[s ^ 1], 0);  // slot free again
@@ -591,12 +678,17 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
             hipEventRecord(up[s ^ 1], ctx->copy_stream);
         }
         hipStreamWaitEvent(ctx->stream, up[s], 0);
-        n[f] = 0;
-        rc = extract_dev_impl(ctx, slot[s], w, h, params, out + (size_t)f * cap, cap, &n[f], nullptr);
-        hipEventRecord(done[s], ctx->stream);
-        if (rc == SIFT_HIP_ERR_NOSPC) worst = rc;
-        else if (rc) { worst = rc; break; }
-    }
+        return slot[s];
+    };
+    auto enqueued = [&](int f) { hipEventRecord(done[f & 1], ctx->stream); };
+    auto reload = [&](int f) -> const float* {
+        hipStreamSynchronize(ctx->copy_stream);
+        hipStreamSynchronize(ctx->stream);
+        if (!hip_ok(ctx, hipMemcpy(slot[0], frames + (size_t)f * px, px * 4, hipMemcpyHostToDevice), "upload frame"))
+            return nullptr;
+        return slot[0];
+    };
+    const int worst = extract_batch_pipelined(ctx, frame_ptr, enqueued, reload, w, h, nframes, params, out, cap, n);
     hipStreamSynchronize(ctx->copy_stream);
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 2; i++) { hipEventDestroy(up[i]); hipEventDestroy(done[i]); }

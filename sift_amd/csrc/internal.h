@@ -45,6 +45,7 @@ struct OctWs {
     hipEvent_t ev_emit = nullptr, ev_done = nullptr;
     DevBuf base, tmp, gau_all, masks, row_cnt, row_off, cand, cand_mask, cand_mm, cand_off, counters, feat, hist;
     DevBuf cand_sub, feat_sub;  // sub-pixel offsets per candidate (float4) / per feature (3 floats)
+    DevBuf feat_alt, feat_sub_alt;  // second output set: a batch fetches frame f-1 while frame f runs
 };
 
 struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-183)
@@ -83,7 +84,10 @@ struct sift_hip_ctx {
     hipEvent_t ev_start = nullptr;
     int cand_cap = 0;
     // pinned host staging
-    int32_t* h_counters = nullptr;
+    int32_t* h_counters = nullptr;      // pinned; the current output set's counters
+    int32_t* h_counters_alt = nullptr;  // ... and the other set's
+    sifthip::DevBuf gcounters_alt;
+    hipEvent_t ev_frame[2] = {nullptr, nullptr};
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
 
