@@ -395,14 +395,13 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
     const unsigned half_shift = (lane & 1) * 16;
     for (int ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
         const Cand cd = cand[ci];
-        if (cd.layer == 0) {  // rejected by the sub-pixel stage (wave-uniform)
-            if (lane == 0) cmask[ci] = 0ull;
-            continue;
-        }
-        const LayerConsts L = lc[cd.layer - 1];
+        // layer 0 = rejected by the sub-pixel stage: an empty window and no firing bin
+        // (an early `continue` here cost the whole loop 18 %)
+        const bool live = cd.layer != 0;
+        const LayerConsts L = lc[max(cd.layer, 1) - 1];
         const int r = L.radius;
         const int n = 2 * r + 1;
-        const int total = n * n;
+        const int total = live ? n * n : 0;
         const float* g1 = gau + (size_t)cd.layer * PX;  // dog[layer] = gau[layer] - gau[layer+1]
         const float* g2 = g1 + PX;
         const float* g = table + L.wts_off;
@@ -519,7 +518,7 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
         float mx = (lane < 36) ? sum : 0.f;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const bool fire = (lane < 36) && ((double)sum >= (double)mx * 0.8);
+        const bool fire = live && (lane < 36) && ((double)sum >= (double)mx * 0.8);
         const unsigned long long m = __ballot(fire);
         if (lane == 0) cmask[ci] = m;
         if (lane < 36) cmm[(size_t)ci * 36 + lane] = sum;

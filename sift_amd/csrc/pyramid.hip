@@ -283,7 +283,7 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         ProfScope ps(ctx, P == 8 ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
         int TH = 16 * P;
-        while (TH > 4 * P && (size_t)(TH + K - 1 + P) * 256 > 48 * 1024) TH >>= 1;
+        while (TH > 4 * P && (size_t)(TH + K - 1 + P) * 256 > 32 * 1024) TH >>= 1;
         const size_t lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
         if (lds <= (size_t)kMaxColLds) {
             dim3 grid((W + 63) / 64, (H + TH - 1) / TH);
