@@ -33,43 +33,64 @@ void launch_gray(sift_hip_ctx* ctx, hipStream_t st, const float* rgb, float* gra
 }
 
 // ---- Scaling::first + Scaling::bilinear, imglib.cpp:203-252 ----------------------
+// Source coordinate of destination index i along an axis of `n` source and `nn`
+// destination samples, and the bilinear terms derived from it (floor/ceil
+// neighbours, the neighbour index clamped where the reference reads past the end).
+struct Axis {
+    int i0, i1;
+    float d1, d2;
+};
+__device__ __forceinline__ Axis first_axis(int i, int n, int nn, float ratio) {
+    float src;
+    if (ratio < 1) {
+        // ((i+0.5f)/Ratio) is a float quotient; the "- 0.5" is done in double
+        src = (float)((double)(((float)i + 0.5f) / ratio) - 0.5);
+    } else {
+        src = (float)i * ((float)n - 1.f) / ((float)nn - 1.f);
+    }
+    const float f0 = floorf(src);
+    Axis a;
+    a.i0 = (int)f0;
+    a.i1 = min((int)ceilf(src), n - 1);
+    a.d1 = src - f0;  // x - x0 with x0 converted back to float
+    a.d2 = 1.f - a.d1;
+    return a;
+}
+
+// A workgroup produces a 256 x FIRST_ROWS tile: every thread keeps the terms of its
+// column, the terms of the tile's rows are computed once into LDS, so a pixel costs
+// four loads, six float operations and a store (the two IEEE divisions per pixel
+// of the direct form made the kernel VALU-bound at 2x its memory time).
+constexpr int FIRST_ROWS = 16;
 __global__ __launch_bounds__(256) void first_kernel(const float* __restrict__ src, int w, int h, float ratio,
                                                     float* __restrict__ dst, int nw, int nh) {
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= nw || j >= nh) return;
-    float srcY, srcX;
-    if (ratio < 1) {
-        // ((j+0.5f)/Ratio) is a float quotient; the "- 0.5" is done in double
-        srcY = (float)((double)(((float)j + 0.5f) / ratio) - 0.5);
-        srcX = (float)((double)(((float)i + 0.5f) / ratio) - 0.5);
-    } else {
-        srcY = (float)j * ((float)h - 1.f) / ((float)nh - 1.f);
-        srcX = (float)i * ((float)w - 1.f) / ((float)nw - 1.f);
+    __shared__ Axis s_row[FIRST_ROWS];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * FIRST_ROWS;
+    if (threadIdx.x < FIRST_ROWS && j0 + threadIdx.x < nh) s_row[threadIdx.x] = first_axis(j0 + threadIdx.x, h, nh, ratio);
+    __syncthreads();
+    if (i >= nw) return;
+    const Axis ax = first_axis(i, w, nw, ratio);
+    const int rows = min(FIRST_ROWS, nh - j0);
+#pragma unroll 4
+    for (int r = 0; r < rows; r++) {
+        const Axis ay = s_row[r];
+        const float* r0 = src + (size_t)ay.i0 * w;
+        const float* r1 = src + (size_t)ay.i1 * w;
+        const float A = r0[ax.i0];
+        const float B = r0[ax.i1];
+        const float C = r1[ax.i0];
+        const float D = r1[ax.i1];
+        const float AB = A * ax.d2 + B * ax.d1;
+        const float CD = C * ax.d2 + D * ax.d1;
+        dst[(size_t)(j0 + r) * nw + i] = AB * ay.d2 + CD * ay.d1;
     }
-    const float fx0 = floorf(srcX), fy0 = floorf(srcY);
-    int x0 = (int)fx0, x1 = (int)ceilf(srcX);
-    int y0 = (int)fy0, y1 = (int)ceilf(srcY);
-    const float dx1 = srcX - fx0;  // x - x0 with x0 converted back to float
-    const float dx2 = 1.f - dx1;
-    const float dy1 = srcY - fy0;
-    const float dy2 = 1.f - dy1;
-    // The reference indexes past the row/image when ceil() leaves it; clamp instead.
-    x1 = min(x1, w - 1);
-    y1 = min(y1, h - 1);
-    const float A = src[(size_t)y0 * w + x0];
-    const float B = src[(size_t)y0 * w + x1];
-    const float C = src[(size_t)y1 * w + x0];
-    const float D = src[(size_t)y1 * w + x1];
-    const float AB = A * dx2 + B * dx1;
-    const float CD = C * dx2 + D * dx1;
-    dst[(size_t)j * nw + i] = AB * dy2 + CD * dy1;
 }
 
 void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, int h, float ratio, float* dst, int nw,
                   int nh) {
     ProfScope ps(ctx, SIFT_HIP_K_RESAMPLE, st);
-    dim3 grid((nw + 63) / 64, (nh + 3) / 4);
+    dim3 grid((nw + 255) / 256, (nh + FIRST_ROWS - 1) / FIRST_ROWS);
     hipLaunchKernelGGL(first_kernel, grid, dim3(256), 0, st, src, w, h, ratio, dst, nw, nh);
 }
 
