@@ -156,7 +156,7 @@ enum {
     SIFT_HIP_K_DESCR = 7,
     SIFT_HIP_K_MATCH = 8,
     SIFT_HIP_K_GRAY = 9,
-    SIFT_HIP_K_BLUR_ROW_SMALL = 10, /* the 2-outputs-per-thread variants used for small octaves */
+    SIFT_HIP_K_BLUR_ROW_SMALL = 10, /* the blur passes of octaves below 3 Mpixel (fewer outputs per thread) */
     SIFT_HIP_K_BLUR_COL_SMALL = 11,
     SIFT_HIP_K_COUNT = 12
 };

@@ -96,7 +96,7 @@ void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, in
 
 // ---- separable blur ----------------------------------------------------------------
 // P = outputs per thread along the filter direction: 8 for large octaves (one LDS
-// read per 8 MACs), 2 for small ones, which otherwise cannot fill 1024 SIMDs.
+// read per 8 MACs), 4 and 2 for smaller ones, which otherwise cannot fill 1024 SIMDs.
 
 template <typename ACC>
 __device__ __forceinline__ void mac(ACC& acc, float a, float g);
@@ -293,7 +293,7 @@ template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                            const float* d_taps, int K) {
     {
-        ProfScope ps(ctx, P == 8 ? SIFT_HIP_K_BLUR_ROW : SIFT_HIP_K_BLUR_ROW_SMALL, st);
+        ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_ROW : SIFT_HIP_K_BLUR_ROW_SMALL, st);
         const int n_in = 64 * P + K - 1 + P;
         const size_t lds = (size_t)(n_in + n_in / P + 1) * sizeof(float);
         dim3 grid((W + 64 * P - 1) / (64 * P), H);
@@ -301,7 +301,7 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
                            K);
     }
     {
-        ProfScope ps(ctx, P == 8 ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
+        ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
         int TH = 16 * P;
         while (TH > 4 * P && (size_t)(TH + K - 1 + P) * 256 > 32 * 1024) TH >>= 1;
@@ -321,8 +321,11 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
 template <typename ACC>
 static void launch_blur_t(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                           const float* d_taps, int K) {
-    if ((size_t)W * H < (size_t)3 << 20)
+    // outputs per thread: fewer for small octaves, which otherwise cannot fill 1024 SIMDs
+    if ((size_t)W * H < (size_t)1 << 20)
         launch_blur_tp<ACC, 2>(ctx, st, src, tmp, dst, W, H, d_taps, K);
+    else if ((size_t)W * H < (size_t)3 << 20)
+        launch_blur_tp<ACC, 4>(ctx, st, src, tmp, dst, W, H, d_taps, K);
     else
         launch_blur_tp<ACC, 8>(ctx, st, src, tmp, dst, W, H, d_taps, K);
 }
