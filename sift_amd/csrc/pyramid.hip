@@ -126,10 +126,26 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
     const int x0 = blockIdx.x * (64 * P);
     const int n_in = 64 * P + K - 1;
     const float* row = in + (size_t)y * W;
-    for (int i = lane; i < n_in; i += 64) {
-        int gx = x0 + i - r;
-        gx = max(0, min(gx, W - 1));
-        s[padx<P>(i)] = row[gx];
+    if (x0 - r >= 0 && x0 - r + n_in <= W) {
+        // interior run: no clamping; loads and LDS writes differ by constants only
+        const float* src = row + (x0 - r) + lane;
+        float* dst = s + padx<P>(lane);
+        constexpr int step = 64 + 64 / P;  // padx(lane + 64) - padx(lane)
+        int i = lane;
+        for (; i + 64 * 3 < n_in; i += 64 * 4, src += 256, dst += 4 * step) {
+            const float a = src[0], b = src[64], c = src[128], d = src[192];
+            dst[0] = a;
+            dst[step] = b;
+            dst[2 * step] = c;
+            dst[3 * step] = d;
+        }
+        for (; i < n_in; i += 64, src += 64, dst += step) dst[0] = src[0];
+    } else {
+        for (int i = lane; i < n_in; i += 64) {
+            int gx = x0 + i - r;
+            gx = max(0, min(gx, W - 1));
+            s[padx<P>(i)] = row[gx];
+        }
     }
     __syncthreads();
     const int base = lane * P;
@@ -190,10 +206,26 @@ __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__
     const int xc = min(x, W - 1);
     const int y0 = blockIdx.y * TH;
     const int rows_in = TH + K - 1;
-    for (int i = wave; i < rows_in; i += 4) {
-        int gy = y0 + i - r;
-        gy = max(0, min(gy, H - 1));
-        s[i * 64 + lane] = in[(size_t)gy * W + xc];
+    if (y0 - r >= 0 && y0 - r + rows_in <= H) {
+        // interior tile: no clamping, four rows of loads in flight per wave
+        const float* src = in + (size_t)(y0 - r + wave) * W + xc;
+        float* dst = s + wave * 64 + lane;
+        const size_t step = (size_t)4 * W;
+        int i = wave;
+        for (; i + 12 < rows_in; i += 16, src += 4 * step, dst += 4 * 256) {
+            const float a = src[0], b = src[step], c = src[2 * step], d = src[3 * step];
+            dst[0] = a;
+            dst[256] = b;
+            dst[512] = c;
+            dst[768] = d;
+        }
+        for (; i < rows_in; i += 4, src += step, dst += 256) dst[0] = src[0];
+    } else {
+        for (int i = wave; i < rows_in; i += 4) {
+            int gy = y0 + i - r;
+            gy = max(0, min(gy, H - 1));
+            s[i * 64 + lane] = in[(size_t)gy * W + xc];
+        }
     }
     __syncthreads();
     for (int c = wave * P; c < TH; c += 4 * P) {
