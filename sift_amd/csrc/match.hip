@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
             if (tile + 1 < RT / 32) load_tile(tile + 1, a_nxt, ci_nxt);
             // the threshold test of chain b is issued after the MFMAs of chain b+1, so
             // the wave never idles on a chain's result while the matrix pipe is free
-            bool hot = false;
             auto chain = [&](int b) {
                 v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[0], bq[b][0], ci_cur, 0, 0, 0);
 #pragma unroll
@@ -219,7 +218,9 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
 #pragma unroll
                 for (int e = 3; e + 1 < 16; e += 2) mx = max(max(mx, acc[e]), acc[e + 1]);
                 mx = max(mx, acc[15]);
-                hot |= (mx >= thr[b]);
+                // one flag per (tile, chain): the slow pass redoes only the 32 x 32 blocks
+                // that can change a top-2, not all NB chains of a flagged tile
+                hotmask |= (__ballot(mx >= thr[b]) != 0ull) ? (1u << (tile * NB + b)) : 0u;
             };
             v16i acc_prev = chain(0);
 #pragma unroll
@@ -230,7 +231,6 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
                 acc_prev = acc_now;
             }
             test(acc_prev, NB - 1);
-            hotmask |= (__ballot(hot) != 0ull) ? (1u << tile) : 0u;
             if (tile + 1 < RT / 32) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) a_cur[s] = a_nxt[s];
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
         // tiles and run the exact top-2 update on every value.
         if (hotmask) {
             for (int tile = 0; tile < RT / 32; tile++) {
-                if (!((hotmask >> tile) & 1u)) continue;
+                const unsigned tb = (hotmask >> (tile * NB)) & ((1u << NB) - 1u);
+                if (!tb) continue;
                 const int row = tile * 32 + jq;
                 v4i a[4];
 #pragma unroll
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
                 }
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
+                    if (!((tb >> b) & 1u)) continue;  // wave-uniform
                     v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[b][0], ci, 0, 0, 0);
 #pragma unroll
                     for (int s = 1; s < 4; s++)
