@@ -94,6 +94,8 @@ void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, in
     hipLaunchKernelGGL(first_kernel, grid, dim3(256), 0, st, src, w, h, ratio, dst, nw, nh);
 }
 
+constexpr int kMaxColLds = 64 * 1024;  // largest LDS tile a blur pass may request
+
 // ---- separable blur ----------------------------------------------------------------
 // P = outputs per thread along the filter direction: 8 for large octaves (one LDS
 // read per 8 MACs), 4 and 2 for smaller ones, which otherwise cannot fill 1024 SIMDs.
@@ -191,6 +193,49 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
         for (int p = 0; p < P; p++)
             if (x0 + base + p < W) o[p] = (float)acc[p];
     }
+}
+
+// Row pass for kernels too long for an LDS run (deep octaves of very large images:
+// thousands of taps over a few pixels): the window slides over global memory.
+template <typename ACC, int P>
+__global__ __launch_bounds__(64) void blur_row_global_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int W, int H, const float* __restrict__ taps, int K) {
+    const int lane = threadIdx.x;
+    const int r = K >> 1;
+    const int y = blockIdx.y;
+    const int xb = (blockIdx.x * 64 + lane) * P;
+    if (xb >= W) return;
+    const float* row = in + (size_t)y * W;
+    auto rd = [&](int xx) -> float { return row[max(0, min(xx, W - 1))]; };
+    ACC acc[P];
+    float win[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        acc[p] = 0;
+        win[p] = rd(xb + p - r);
+    }
+    int k = 0;
+    for (; k + P <= K; k += P) {
+#pragma unroll
+        for (int u = 0; u < P; u++) {
+            const float g = taps[k + u];
+#pragma unroll
+            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+            win[u] = rd(xb + k + u + P - r);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < P; u++) {
+        if (k + u < K) {
+            const float g = taps[k + u];
+#pragma unroll
+            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
+            win[u] = rd(xb + k + u + P - r);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++)
+        if (xb + p < W) out[(size_t)y * W + xb + p] = (float)acc[p];
 }
 
 // Column pass: a 256-thread workgroup owns 64 columns x TH rows; LDS holds the
@@ -319,7 +364,6 @@ __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __res
     }
 }
 
-constexpr int kMaxColLds = 64 * 1024;  // largest LDS tile the column pass may request
 
 template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
@@ -329,8 +373,12 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         const int n_in = 64 * P + K - 1 + P;
         const size_t lds = (size_t)(n_in + n_in / P + 1) * sizeof(float);
         dim3 grid((W + 64 * P - 1) / (64 * P), H);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC, P>), grid, dim3(64), lds, st, src, tmp, W, H, d_taps,
-                           K);
+        if (lds <= (size_t)kMaxColLds)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC, P>), grid, dim3(64), lds, st, src, tmp, W, H,
+                               d_taps, K);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_global_kernel<ACC, P>), grid, dim3(64), 0, st, src, tmp, W, H,
+                               d_taps, K);
     }
     {
         ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);

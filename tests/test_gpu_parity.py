@@ -39,6 +39,13 @@ def test_gau_blur_long_kernel_uses_global_column_pass(sift, oracle):
     assert np.array_equal(bits(sift.gau_blur(img, 72.4)), bits(oracle.gau_blur(img, 72.4)))
 
 
+def test_gau_blur_very_long_kernel_uses_global_row_pass(sift, oracle):
+    # sigma 2500 -> 15001 taps, as in octave 8+ of a 16384^2 image: too long for an LDS run
+    rng = np.random.default_rng(12)
+    img = rng.random((30, 40), dtype=np.float32)
+    assert np.array_equal(bits(sift.gau_blur(img, 2500.0)), bits(oracle.gau_blur(img, 2500.0)))
+
+
 def test_gau_blur_fast_mode_close(sift, oracle):
     rng = np.random.default_rng(9)
     img = rng.random((120, 160), dtype=np.float32)
