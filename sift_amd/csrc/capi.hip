@@ -230,7 +230,8 @@ static int get_lane(sift_hip_ctx* ctx, int oi, OctWs** out) {
 }
 
 // Gaussian levels of octave `oi` from the gray image on the device, on stream st.
-static int run_octave_pyramid(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, const float* d_gray, int oi) {
+static int run_octave_pyramid(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, const float* d_gray, int oi,
+                              int skip_levels = 0) {
     const Plan& pl = ctx->plan;
     const OctavePlan& oc = pl.oct[oi];
     const size_t PX = (size_t)oc.W * oc.H;
@@ -244,7 +245,7 @@ static int run_octave_pyramid(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, cons
     float* gau = (float*)ws.gau_all.p;
     const float* taps = (const float*)ctx->table.p;
     launch_first(ctx, st, d_gray, pl.w, pl.h, oc.curr_size, base, oc.W, oc.H);
-    for (int i = 0; i < pyWidth; i++) {
+    for (int i = 0; i < pyWidth - skip_levels; i++) {
         const float* src = (i == 0) ? base : gau + (size_t)(i - 1) * PX;
         launch_blur(ctx, st, src, tmp, gau + (size_t)i * PX, oc.W, oc.H, taps + oc.tap_off[i], oc.tap_len[i],
                     pl.prm.blur_mode);
@@ -286,6 +287,9 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         if ((rc = ensure(ctx, ws->cand_mm, (size_t)cand_cap * 36 * sizeof(float)))) return rc;
         if ((rc = ensure(ctx, ws->cand_off, (size_t)cand_cap * sizeof(int)))) return rc;
         if ((rc = ensure(ctx, ws->counters, CNT_SLOTS * sizeof(int)))) return rc;
+        if ((rc = ensure(ctx, ws->counters2, CNT_SLOTS * sizeof(int)))) return rc;
+        if ((rc = ensure(ctx, ws->row_off2, (size_t)oc.H * 4))) return rc;
+        if ((rc = ensure(ctx, ws->cand2, (size_t)cand_cap * sizeof(Cand)))) return rc;
         if ((rc = ensure(ctx, ws->feat, (size_t)std::max(1, feat_cap) * sizeof(sift_hip_feat)))) return rc;
         if (want_hist && (rc = ensure(ctx, ws->hist, (size_t)std::max(1, feat_cap) * 128 * sizeof(float)))) return rc;
         if (prm.subpixel) {
@@ -315,10 +319,18 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         ws.stream = st;
         const OctavePlan& oc = pl.oct[oi];
         const size_t PX = (size_t)oc.W * oc.H;
-        rc = run_octave_pyramid(ctx, ws, st, d_gray, oi);
+        // The last Gaussian level is only read next to top-layer extrema: unless the
+        // sub-pixel stage (which reads it around moved points) is on or its kernel is very
+        // long, it is not built as an image.
+        const int top_K = oc.tap_len[prm.intvls + 2];
+        // (a workgroup sweeps K+2 rows of K+2 inputs per candidate: beyond ~1000 taps, i.e. in
+        // octaves of a few thousand pixels, building the level is cheaper)
+        const bool lazy = !prm.subpixel && !ctx->full_top_level && top_K <= 1024;
+        rc = run_octave_pyramid(ctx, ws, st, d_gray, oi, lazy ? 1 : 0);
         if (!rc) {
             const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
-            launch_detect(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap);
+            launch_detect(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap,
+                          lazy ? (const float*)ctx->table.p + oc.tap_off[prm.intvls + 2] : nullptr, top_K);
             if (prm.subpixel) launch_refine(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, prm.contr_thr);
             launch_orient(ctx, ws, PX, oc.W, d_lc, (const float*)ctx->table.p);
             launch_emit(ctx, ws, oi, oc.curr_size, d_lc, feat_cap, prm.subpixel != 0);
@@ -521,6 +533,7 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     ctx->device = device;
     // SIFT_HIP_SERIAL=1: all octaves on one stream (clean per-kernel durations under a tracer)
     if (const char* e = std::getenv("SIFT_HIP_SERIAL")) ctx->force_serial = (e[0] == '1');
+    if (const char* e = std::getenv("SIFT_HIP_FULL_TOP")) ctx->full_top_level = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -544,7 +557,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     for (OctWs& ws : ctx->lanes) {
         if (ws.own_stream && ws.stream) hipStreamSynchronize(ws.stream);
         DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
-                        &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist, &ws.cand_sub, &ws.feat_sub, &ws.feat_alt, &ws.feat_sub_alt};
+                        &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist, &ws.cand_sub, &ws.feat_sub, &ws.feat_alt, &ws.feat_sub_alt, &ws.row_off2, &ws.cand2, &ws.counters2};
         for (DevBuf* b : wb)
             if (b->p) hipFree(b->p);
         if (ws.ev_emit) hipEventDestroy(ws.ev_emit);

@@ -9,6 +9,8 @@
 // The candidate order (layer, row, column) and the feature order (candidate,
 // bin) reproduce the append order of the reference's scan (Sift.cpp:173-200,
 // :285-293), so the output array equals its linked list copied out (:207-224).
+#include <algorithm>
+
 #include "internal.h"
 
 namespace sifthip {
@@ -25,13 +27,16 @@ constexpr int kMaxIntvls = 8;
 // ---- findMaxMin (Sift.cpp:86-104) + harris_corner (Sift.cpp:105-129) -------------
 // d = LDS DoG tile of layer li centred on the pixel (row stride DET_LW, layer
 // stride DET_LH*DET_LW); v = its value, already past |v| > thr.
-__device__ __forceinline__ bool is_keypoint(const float* d, float v, float rad) {
+// upper = false leaves the layer above out of the extremum test (it is checked
+// later, only for the pixels that pass everything else: see top_check_kernel).
+__device__ __forceinline__ bool is_keypoint(const float* d, float v, float rad, bool upper) {
     constexpr int LS = DET_LH * DET_LW;
     // "no neighbour is larger" (v > 0) / "no neighbour is smaller" (v < 0), ties
     // allowed, as max/min over the 27 values (the centre itself changes nothing)
     float mx = v, mn = v;
 #pragma unroll
     for (int k = -1; k <= 1; k++) {
+        if (k == 1 && !upper) break;
 #pragma unroll
         for (int j = -1; j <= 1; j++) {
             const float a = d[k * LS + j * DET_LW - 1], b = d[k * LS + j * DET_LW], c = d[k * LS + j * DET_LW + 1];
@@ -54,12 +59,15 @@ __device__ __forceinline__ bool is_keypoint(const float* d, float v, float rad) 
 
 // grid = (ceil(W/64), ceil(H/DET_TR)).  Writes every mask word of its tile (zeros
 // included) and adds the per-(layer,row) counts into row_cnt (zeroed beforehand).
-template <int NLAY>  // intvls + 2 when known at compile time, else 0
+// NLAY = number of DoG layers staged when known at compile time, else 0.  With
+// lazy_top the last Gaussian level does not exist: intvls + 1 DoG layers are
+// staged and the top layer's marks are tentative (its upper neighbours untested).
+template <int NLAY>
 __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
                                                           int intvls, const LayerConsts* __restrict__ lc, float thr,
                                                           int WW, unsigned long long* __restrict__ masks,
-                                                          int* __restrict__ row_cnt) {
-    extern __shared__ float s_dog[];  // [intvls+2][DET_LH][DET_LW]
+                                                          int* __restrict__ row_cnt, int lazy_top) {
+    extern __shared__ float s_dog[];  // [nlay][DET_LH][DET_LW]
     constexpr int LS = DET_LH * DET_LW;
     // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.
     // Remap so that one XCD owns a contiguous run of tiles: the halo columns and
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restric
     const int tid_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int tx = tid_lin % WW, ty = tid_lin / WW;
     const int x0 = tx * 64, y0 = ty * DET_TR;
-    const int nlay = intvls + 2;
+    const int nlay = intvls + 2 - lazy_top;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         // one wavefront per tile row: 64 coalesced columns + the two halo columns
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restric
             // scan bounds of Sift.cpp:178-179: r+1 <= y < H-r-1, r+1 <= x < W-r-1
             bool hit = (H >= 2 * rad + 3) && (W >= 2 * rad + 3) && y >= rad + 1 && y < H - rad - 1 && x >= rad + 1 &&
                        x < W - rad - 1 && (fabsf(v) > thr);
-            if (hit) hit = is_keypoint(d, v, (float)rad);
+            if (hit) hit = is_keypoint(d, v, (float)rad, !(lazy_top && l == intvls - 1));
             const unsigned long long m = __ballot(hit);
             if (lane == 0) {
                 masks[((size_t)l * H + y) * WW + tx] = m;
@@ -228,6 +236,97 @@ __global__ __launch_bounds__(64) void expand_rows_kernel(const unsigned long lon
             pos++;
         }
         running += __shfl(inc, 63);
+    }
+}
+
+// ---- the last Gaussian level, only where it is looked at --------------------------
+// gau[intvls+2] feeds nothing but dog[intvls+1], and that layer is only ever
+// compared with the 3x3 neighbourhood of a top-layer pixel that has already passed
+// the contrast, same-layer, lower-layer and edge tests: a few thousand pixels
+// instead of every pixel of the most expensive blur (the longest kernel).  For each
+// such pixel a workgroup recomputes the level at its 3x3 neighbourhood exactly as
+// the two blur passes would (row pass values of the K+2 rows involved, rounded to
+// float, then the column pass; same products, same order, same edge clamping),
+// finishes the extremum test and clears the pixel's mask bit if it fails.
+__global__ __launch_bounds__(256) void top_check_kernel(const float* __restrict__ g_lo, const float* __restrict__ g_hi,
+                                                        int W, int H, const float* __restrict__ taps, int K,
+                                                        const Cand* __restrict__ cand2,
+                                                        const int* __restrict__ counters2, int WW,
+                                                        unsigned long long* __restrict__ masks_top,
+                                                        int* __restrict__ row_cnt_top) {
+    extern __shared__ float s_tmp[];  // [3][K + 2] row-pass values
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int r5 = K >> 1;
+    const int nt = K + 2;
+    const int ncand = counters2[CNT_NCAND];
+    for (int ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
+        const Cand cd = cand2[ci];
+        const int x = cd.x, y = cd.y;
+        if (tid == 0) s_bad = 0;
+        // Row pass: thread t owns input row y-1-r5+t (clamped as the blur clamps) and
+        // produces its three outputs at columns x-1, x, x+1 from one sweep over the
+        // K+2 inputs they share.
+        const int c0 = x - 1 - r5;  // column of input offset 0
+        const bool inside = c0 >= 0 && c0 + K + 2 <= W;
+        for (int t = tid; t < nt; t += nthr) {
+            const int row = min(max(y - 1 - r5 + t, 0), H - 1);
+            const float* src = g_hi + (size_t)row * W;
+            double a0 = 0, a1 = 0, a2 = 0;
+            if (inside) {
+                const float* sp = src + c0;
+                float v0 = sp[0], v1 = sp[1];
+#pragma unroll 8
+                for (int k = 0; k < K; k++) {
+                    const float v2 = sp[k + 2];
+                    const float g = taps[k];
+                    const float p0 = v0 * g, p1 = v1 * g, p2 = v2 * g;
+                    a0 += (double)p0;
+                    a1 += (double)p1;
+                    a2 += (double)p2;
+                    v0 = v1;
+                    v1 = v2;
+                }
+            } else {
+                auto ld = [&](int j) { return src[min(max(c0 + j, 0), W - 1)]; };
+                float v0 = ld(0), v1 = ld(1);
+                for (int k = 0; k < K; k++) {
+                    const float v2 = ld(k + 2);
+                    const float g = taps[k];
+                    const float p0 = v0 * g, p1 = v1 * g, p2 = v2 * g;
+                    a0 += (double)p0;
+                    a1 += (double)p1;
+                    a2 += (double)p2;
+                    v0 = v1;
+                    v1 = v2;
+                }
+            }
+            s_tmp[t] = (float)a0;
+            s_tmp[nt + t] = (float)a1;
+            s_tmp[2 * nt + t] = (float)a2;
+        }
+        __syncthreads();
+        // Column pass at the nine positions, then the part of findMaxMin that was left out.
+        if (tid < 9) {
+            const int c = tid % 3, oyi = tid / 3;
+            const float* col = s_tmp + c * nt + oyi;
+            double acc = 0;
+            for (int k = 0; k < K; k++) {
+                const float prod = col[k] * taps[k];
+                acc += (double)prod;
+            }
+            const size_t p = (size_t)(y - 1 + oyi) * W + (x - 1 + c);
+            const float up = g_hi[p] - (float)acc;  // dog[top+1] at this neighbour
+            const size_t pc = (size_t)y * W + x;
+            const float v = g_lo[pc] - g_hi[pc];    // dog[top] at the pixel
+            if ((v > 0.f && v < up) || (v < 0.f && v > up)) s_bad = 1;
+        }
+        __syncthreads();
+        if (tid == 0 && s_bad) {
+            atomicAnd(&masks_top[(size_t)y * WW + (x >> 6)], ~(1ull << (x & 63)));
+            atomicSub(&row_cnt_top[y], 1);
+        }
+        __syncthreads();
     }
 }
 
@@ -591,17 +690,35 @@ __global__ __launch_bounds__(256) void emit_kernel(const Cand* __restrict__ cand
 }
 
 void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
-                   float thr, int cand_cap) {
+                   float thr, int cand_cap, const float* d_top_taps, int top_K) {
     const int WW = (W + 63) / 64;
     const int nrows = intvls * H;
+    const int lazy = d_top_taps != nullptr;
     {
         ProfScope ps(ctx, SIFT_HIP_K_DETECT, ws.stream);
         hipMemsetAsync(ws.row_cnt.p, 0, (size_t)nrows * sizeof(int), ws.stream);
-        const size_t lds = (size_t)(intvls + 2) * DET_LH * DET_LW * sizeof(float);
-        auto kern = intvls == 3 ? detect_tile_kernel<5> : detect_tile_kernel<0>;
+        const int nlay = intvls + 2 - lazy;
+        const size_t lds = (size_t)nlay * DET_LH * DET_LW * sizeof(float);
+        auto kern = nlay == 5 ? detect_tile_kernel<5> : nlay == 4 ? detect_tile_kernel<4> : detect_tile_kernel<0>;
         hipLaunchKernelGGL(kern, dim3(WW, (H + DET_TR - 1) / DET_TR), dim3(256), lds, ws.stream,
                            (const float*)ws.gau_all.p, PX, W, H, intvls, d_lc, thr, WW,
-                           (unsigned long long*)ws.masks.p, (int*)ws.row_cnt.p);
+                           (unsigned long long*)ws.masks.p, (int*)ws.row_cnt.p, lazy);
+        if (lazy) {
+            // tentative top-layer marks -> list -> exact check against the level that was not built
+            const int top = intvls - 1;  // 0-based index of the top layer in masks / row_cnt
+            unsigned long long* masks_top = (unsigned long long*)ws.masks.p + (size_t)top * H * WW;
+            int* row_cnt_top = (int*)ws.row_cnt.p + (size_t)top * H;
+            hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, ws.stream, (const int*)row_cnt_top,
+                               (int*)ws.row_off2.p, H, cand_cap, (int*)ws.counters2.p, (int*)ctx->gcounters.p);
+            hipLaunchKernelGGL(expand_rows_kernel, dim3(H), dim3(64), 0, ws.stream, (const unsigned long long*)masks_top,
+                               (const int*)row_cnt_top, (const int*)ws.row_off2.p, H, WW, (Cand*)ws.cand2.p, cand_cap);
+            const float* g_lo = (const float*)ws.gau_all.p + (size_t)intvls * PX;
+            const size_t lds2 = (size_t)3 * (top_K + 2) * sizeof(float);
+            const int nthr = std::min(256, (top_K + 2 + 63) / 64 * 64);  // one thread per input row
+            hipLaunchKernelGGL(top_check_kernel, dim3(256 * 32), dim3(nthr), lds2, ws.stream, g_lo, g_lo + PX, W, H,
+                               d_top_taps, top_K, (const Cand*)ws.cand2.p, (const int*)ws.counters2.p, WW, masks_top,
+                               row_cnt_top);
+        }
     }
     {
         ProfScope ps(ctx, SIFT_HIP_K_COMPACT, ws.stream);

@@ -45,6 +45,7 @@ struct OctWs {
     hipEvent_t ev_emit = nullptr, ev_done = nullptr;
     DevBuf base, tmp, gau_all, masks, row_cnt, row_off, cand, cand_mask, cand_mm, cand_off, counters, feat, hist;
     DevBuf cand_sub, feat_sub;  // sub-pixel offsets per candidate (float4) / per feature (3 floats)
+    DevBuf row_off2, cand2, counters2;  // tentative top-layer candidates (the last level is built only there)
     DevBuf feat_alt, feat_sub_alt;  // second output set: a batch fetches frame f-1 while frame f runs
 };
 
@@ -94,6 +95,7 @@ struct sift_hip_ctx {
     // profiling
     bool profiling = false;
     bool force_serial = false;
+    bool full_top_level = false;  // SIFT_HIP_FULL_TOP=1: build the last Gaussian level as an image (A/B measurements)
     int side_priority = 1;          // 1: the small-octave stream is created with the urgent priority
     struct Ev { int cls; hipEvent_t a, b; };
     std::vector<Ev> events;
@@ -138,7 +140,7 @@ struct LayerConsts {  // per DoG layer 1..intvls of one octave
 // ws.gau_all: level-major Gaussian images of the octave, PX pixels per level
 // (DoG values are recomputed from adjacent levels, never stored).
 void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
-                   float thr, int cand_cap);
+                   float thr, int cand_cap, const float* d_top_taps, int top_K);
 void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
                    float contr_thr);
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table);

@@ -205,9 +205,34 @@ def test_profile_counts_launches(sift):
     sift.extract(img, SiftParams(octaves=1))
     prof = sift.profile_read(reset=True)
     sift.profile(False)
-    # a 512x384 octave is below the large-octave threshold: the 2-outputs-per-thread kernels run
-    assert prof["blur_row_small"][1] == 6 and prof["blur_col_small"][1] == 6 and prof["resample"][1] == 1
+    # a 512x384 octave is below the large-octave threshold: the small-octave kernels run.
+    # Five of the six Gaussian levels are built as images; the last one is evaluated
+    # only around top-layer extrema (with the sub-pixel stage on, all six are built).
+    assert prof["blur_row_small"][1] == 5 and prof["blur_col_small"][1] == 5 and prof["resample"][1] == 1
     assert prof["blur_row_small"][0] > 0 and prof["blur_row"][1] == 0
+    sift.profile(True)
+    sift.extract(img, SiftParams(octaves=1, subpixel=1))
+    prof = sift.profile_read(reset=True)
+    sift.profile(False)
+    assert prof["blur_row_small"][1] == 6 and prof["blur_col_small"][1] == 6
+
+
+def test_lazy_top_level_equals_full_level(sift):
+    """The last Gaussian level evaluated only at top-layer extrema must give the
+    features of the full-image evaluation (the library's A/B switch builds it)."""
+    import os
+
+    img = sift_amd.blob_image(640, 480, seed=3)
+    f, h = sift.extract(img, want_hist=True)
+    os.environ["SIFT_HIP_FULL_TOP"] = "1"
+    try:
+        other = sift_amd.SiftHip(0)
+        f2, h2 = other.extract(img, want_hist=True)
+        other.close()
+    finally:
+        del os.environ["SIFT_HIP_FULL_TOP"]
+    assert (f["kai"] == 3).sum() > 20
+    assert f.tobytes() == f2.tobytes() and np.array_equal(h, h2)
 
 
 # ---- against the committed golden vectors (reference object code outputs) ---------------
