@@ -115,15 +115,14 @@ def main():
         px = pyramid_pixels(W, H, args.octaves)
         levels = prm.intvls + 3
         # algorithmic bytes of the pyramid+DoG stage: 68 B per octave pixel = 6 levels x (4 B read
-        # + 4 B write) + 5 DoG layers x 4 B; the stage is 2 launches per level (row pass, column
-        # pass), so one launch over PX pixels carries 68/12 B per pixel.
+        # + 4 B write) + 5 DoG layers x 4 B.  One blur pass (a launch) over PX pixels reads and
+        # writes every pixel once: 8 B per pixel.
         stage_bytes_per_px = levels * 8 + (levels - 1) * 4
-        per_launch_bytes_per_px = stage_bytes_per_px / (2.0 * levels)
         big = [p for p in px if p >= (3 << 20)]          # octaves handled by the 8-outputs-per-thread kernels
         dom = max(("blur_col", "blur_row"), key=lambda k: prof[k][0])
         n_dom = prof[dom][1] // nprof
         avg_ms = prof[dom][0] / max(prof[dom][1], 1)
-        alg_launch = per_launch_bytes_per_px * (sum(big) * levels / max(n_dom, 1))
+        alg_launch = 8.0 * sum(big) / max(len(big), 1)   # the class's launches differ only in tap count
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9
         blur_keys = ("blur_row", "blur_col", "blur_row_small", "blur_col_small")
         t_stage = sum(prof[k][0] for k in blur_keys) / nprof
@@ -144,10 +143,13 @@ def main():
                                "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, per launch; profiles/" + os.path.basename(tpath)
         # VALU floor of the exact blur: 4.86 ns per wave-level (v_mul_f32, v_cvt_f64_f32, v_add_f64)
         # triple per SIMD (tools/microbench_valu.hip), 1024 SIMDs
+        # levels built as images: the library evaluates the last level only around top-layer
+        # extrema (unless the sub-pixel stage is on), which the launch count shows
+        built = (sum(prof[k][1] for k in blur_keys) // nprof) // (2 * len(px))
         taps = 0
         size = 2.0
         for o in range(args.octaves):
-            for i in range(levels):
+            for i in range(built):
                 sig = 1.6 * (2.0 ** 0.5) ** i * (2.0 / size)
                 taps += px[o] * 2 * (int(round(6 * sig + 1)) | 1)
             size /= 2.0
@@ -165,6 +167,7 @@ def main():
             "avg_launch_ms": round(avg_ms, 5),
             "pyramid_stage": {
                 "launches_per_frame": sum(prof[k][1] for k in blur_keys) // nprof,
+                "levels_built_as_images": built,
                 "algorithmic_bytes_per_frame": alg_stage,
                 "ms_per_frame": round(t_stage, 4),
                 "achieved_GBps": round(alg_stage / (t_stage * 1e-3) / 1e9, 1),
@@ -176,7 +179,9 @@ def main():
             "stage_ms_per_frame": {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1]},
             "note": "blur_mode 0 keeps the reference's float-product / double-accumulate arithmetic bit for bit, "
                     "which makes the blur fp64-VALU-bound (v_mul_f32 + v_cvt_f64_f32 + v_add_f64 per tap), not "
-                    "HBM-bound; frac_of_valu_floor is the efficiency against that bound",
+                    "HBM-bound; frac_of_valu_floor is the efficiency against that bound for the levels that are "
+                    "built as images (the last level of each octave is evaluated only at the 3x3 neighbourhoods "
+                    "of top-layer extrema, inside the detect class)",
         }
 
     # ---- side measurements (rank 0, outside the timed region; none of them is `value`) -------
