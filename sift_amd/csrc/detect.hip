@@ -191,19 +191,21 @@ __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__
                                                          int nrows, int cand_cap, int* __restrict__ counters,
                                                          int* __restrict__ gcounters) {
     __shared__ int s_warp[40];
-    int running = 0;
-    for (int b = 0; b < nrows; b += 1024) {
-        const int i = b + threadIdx.x;
-        const int v = (i < nrows) ? row_cnt[i] : 0;
-        int total;
-        const int ex = block_excl_scan_1024(v, s_warp, total);
-        if (i < nrows) row_off[i] = running + ex;
-        running += total;
+    // thread t owns the rows [t*C, (t+1)*C): one workgroup scan for any row count
+    const int C = (nrows + 1023) / 1024;
+    const int r0 = threadIdx.x * C, r1 = min(r0 + C, nrows);
+    int mine = 0;
+    for (int i = r0; i < r1; i++) mine += row_cnt[i];
+    int total;
+    int run = block_excl_scan_1024(mine, s_warp, total);
+    for (int i = r0; i < r1; i++) {
+        row_off[i] = run;
+        run += row_cnt[i];
     }
     if (threadIdx.x == 0) {
-        counters[CNT_NCAND_TOTAL] = running;
-        counters[CNT_NCAND] = min(running, cand_cap);
-        if (running > cand_cap) atomicMax(&gcounters[G_CAND_OVERFLOW], running);
+        counters[CNT_NCAND_TOTAL] = total;
+        counters[CNT_NCAND] = min(total, cand_cap);
+        if (total > cand_cap) atomicMax(&gcounters[G_CAND_OVERFLOW], total);
     }
 }
 
@@ -633,16 +635,18 @@ __global__ __launch_bounds__(1024) void emit_scan_kernel(const unsigned long lon
     __shared__ int s_warp[40];
     const int ncand = counters[CNT_NCAND];
     const int begin = 0;  // every octave fills its own feature buffer
-    int running = begin;
-    for (int b = 0; b < ncand; b += 1024) {
-        const int i = b + threadIdx.x;
-        const int v = (i < ncand) ? __popcll(cmask[i]) : 0;
-        int total;
-        const int ex = block_excl_scan_1024(v, s_warp, total);
-        if (i < ncand) cand_off[i] = running + ex;
-        running += total;
+    // thread t owns the candidates [t*C, (t+1)*C): one workgroup scan for any count
+    const int C = (ncand + 1023) / 1024;
+    const int c0 = threadIdx.x * C, c1 = min(c0 + C, ncand);
+    int mine = 0;
+    for (int i = c0; i < c1; i++) mine += __popcll(cmask[i]);
+    int total;
+    int run = begin + block_excl_scan_1024(mine, s_warp, total);
+    for (int i = c0; i < c1; i++) {
+        cand_off[i] = run;
+        run += __popcll(cmask[i]);
     }
-    __syncthreads();
+    const int running = begin + total;
     if (threadIdx.x == 0) {
         counters[CNT_OCT_BEGIN] = begin;
         counters[CNT_OCT_END] = running;
