@@ -142,6 +142,18 @@ int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t
 int sift_hip_match_u8_dev(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
                           int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
 
+/* Multi-GPU form, one process per GPU: every rank passes its own shard of the references
+ * (the same nr_local on every rank) and its own queries; the shards are all-gathered with
+ * ncclAllGather on the caller's communicator (comm: an ncclComm_t of nranks ranks; RCCL over
+ * xGMI) into a buffer of the context, on the context's stream, and the rank's queries are
+ * matched against all nranks * nr_local references.  best holds indices into the gathered
+ * order (rank-major: rank k's reference i is k * nr_local + i).  No counterpart in the
+ * reference, which is single-process; the comparison semantics are those of
+ * sift_hip_match_u8.  No host synchronisation. */
+int sift_hip_match_u8_sharded(sift_hip_ctx* ctx, void* comm, int nranks, const uint8_t* d_q, int nq,
+                              const uint8_t* d_r_local, int nr_local, float ratio, int ratio_form, int32_t* d_best,
+                              int32_t* d_d1, int32_t* d_d2);
+
 /* ---- measurement ------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; totals are kept per kernel class. */

@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
         "sift_hip_pyramid_octaves": (C.c_int, [C.c_int, C.c_int]),
         "sift_hip_match_u8": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_match_u8_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+        "sift_hip_match_u8_sharded": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
         "sift_hip_kernel_class_name": (C.c_char_p, [C.c_int]),

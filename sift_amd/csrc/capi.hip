@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <dlfcn.h>
+
 #include "internal.h"
 
 using namespace sifthip;
@@ -565,7 +567,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
         if (ws.own_stream && ws.stream) hipStreamDestroy(ws.stream);
     }
     DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->table, &ctx->layer_consts,
-                      &ctx->gcounters, &ctx->gcounters_alt, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
+                      &ctx->gcounters, &ctx->gcounters_alt, &ctx->gathered, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -793,6 +795,57 @@ int sift_hip_match_u8_dev(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const u
     int rc = run_match(ctx, d_q, nq, d_r, nr, ratio, ratio_form, d_best, d_d1, d_d2);
     if (rc) return rc;
     return check_async(ctx, "match launch");
+}
+
+// RCCL is reached through the copy the calling process already uses (the
+// communicator belongs to it): the symbol is looked up at call time, so the
+// library itself carries no link dependency on a particular librccl.
+typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static allgather_fn find_allgather() {
+    static allgather_fn fn = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        fn = (allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!fn) {
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                    fn = (allgather_fn)dlsym(h, "ncclAllGather");
+                    if (fn) break;
+                }
+            }
+        }
+    }
+    return fn;
+}
+
+int sift_hip_match_u8_sharded(sift_hip_ctx* ctx, void* comm, int nranks, const uint8_t* d_q, int nq,
+                              const uint8_t* d_r_local, int nr_local, float ratio, int ratio_form, int32_t* d_best,
+                              int32_t* d_d1, int32_t* d_d2) {
+    if (bad_ctx(ctx) || !comm || nranks < 1 || nq < 0 || nr_local < 0 || (nq > 0 && (!d_q || !d_best)) ||
+        (nr_local > 0 && !d_r_local))
+        return SIFT_HIP_ERR_ARG;
+    if (ratio_form != 0 && ratio_form != 1) return SIFT_HIP_ERR_ARG;
+    if ((long long)nr_local * nranks > INT32_MAX) return SIFT_HIP_ERR_LIMIT;
+    const int nr_all = nr_local * nranks;
+    int rc = ensure(ctx, ctx->gathered, std::max<size_t>(1, (size_t)nr_all * 128));
+    if (rc) return rc;
+    if (nr_local > 0) {
+        allgather_fn ag = find_allgather();
+        if (!ag) {
+            ctx->last_error = "ncclAllGather not found in this process (load RCCL before calling)";
+            return SIFT_HIP_ERR_HIP;
+        }
+        const int nrc = ag(d_r_local, ctx->gathered.p, (size_t)nr_local * 128, /*ncclUint8*/ 1, comm, ctx->stream);
+        if (nrc != 0) {
+            ctx->last_error = "ncclAllGather failed with code " + std::to_string(nrc);
+            return SIFT_HIP_ERR_HIP;
+        }
+    }
+    if (nq == 0) return SIFT_HIP_OK;
+    rc = run_match(ctx, d_q, nq, (const uint8_t*)ctx->gathered.p, nr_all, ratio, ratio_form, d_best, d_d1, d_d2);
+    if (rc) return rc;
+    return check_async(ctx, "sharded match launch");
 }
 
 int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t* r, int nr, float ratio,

@@ -88,6 +88,7 @@ struct sift_hip_ctx {
     int32_t* h_counters = nullptr;      // pinned; the current output set's counters
     int32_t* h_counters_alt = nullptr;  // ... and the other set's
     sifthip::DevBuf gcounters_alt;
+    sifthip::DevBuf gathered;  // all ranks' reference descriptors (sharded match)
     hipEvent_t ev_frame[2] = {nullptr, nullptr};
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
