@@ -256,12 +256,16 @@ __global__ __launch_bounds__(256) void top_check_kernel(const float* __restrict_
                                                         const int* __restrict__ counters2, int WW,
                                                         unsigned long long* __restrict__ masks_top,
                                                         int* __restrict__ row_cnt_top) {
-    extern __shared__ float s_tmp[];  // [3][K + 2] row-pass values
+    extern __shared__ float s_tmp[];  // [3][K + 2] row-pass values, then the K taps
     __shared__ int s_bad;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int r5 = K >> 1;
     const int nt = K + 2;
     const int ncand = counters2[CNT_NCAND];
+    if ((int)blockIdx.x >= ncand) return;
+    float* s_taps = s_tmp + 3 * nt;
+    for (int k = tid; k < K; k += nthr) s_taps[k] = taps[k];
+    __syncthreads();
     for (int ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
         const Cand cd = cand2[ci];
         const int x = cd.x, y = cd.y;
@@ -278,10 +282,10 @@ __global__ __launch_bounds__(256) void top_check_kernel(const float* __restrict_
             if (inside) {
                 const float* sp = src + c0;
                 float v0 = sp[0], v1 = sp[1];
-#pragma unroll 8
+#pragma unroll 16
                 for (int k = 0; k < K; k++) {
                     const float v2 = sp[k + 2];
-                    const float g = taps[k];
+                    const float g = s_taps[k];
                     const float p0 = v0 * g, p1 = v1 * g, p2 = v2 * g;
                     a0 += (double)p0;
                     a1 += (double)p1;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void top_check_kernel(const float* __restrict_
                 float v0 = ld(0), v1 = ld(1);
                 for (int k = 0; k < K; k++) {
                     const float v2 = ld(k + 2);
-                    const float g = taps[k];
+                    const float g = s_taps[k];
                     const float p0 = v0 * g, p1 = v1 * g, p2 = v2 * g;
                     a0 += (double)p0;
                     a1 += (double)p1;
@@ -313,8 +317,9 @@ __global__ __launch_bounds__(256) void top_check_kernel(const float* __restrict_
             const int c = tid % 3, oyi = tid / 3;
             const float* col = s_tmp + c * nt + oyi;
             double acc = 0;
+#pragma unroll 8
             for (int k = 0; k < K; k++) {
-                const float prod = col[k] * taps[k];
+                const float prod = col[k] * s_taps[k];  // LDS reads run ahead of the ordered additions
                 acc += (double)prod;
             }
             const size_t p = (size_t)(y - 1 + oyi) * W + (x - 1 + c);
@@ -717,7 +722,7 @@ void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
             hipLaunchKernelGGL(expand_rows_kernel, dim3(H), dim3(64), 0, ws.stream, (const unsigned long long*)masks_top,
                                (const int*)row_cnt_top, (const int*)ws.row_off2.p, H, WW, (Cand*)ws.cand2.p, cand_cap);
             const float* g_lo = (const float*)ws.gau_all.p + (size_t)intvls * PX;
-            const size_t lds2 = (size_t)3 * (top_K + 2) * sizeof(float);
+            const size_t lds2 = (size_t)(3 * (top_K + 2) + top_K) * sizeof(float);
             const int nthr = std::min(256, (top_K + 2 + 63) / 64 * 64);  // one thread per input row
             hipLaunchKernelGGL(top_check_kernel, dim3(256 * 32), dim3(nthr), lds2, ws.stream, g_lo, g_lo + PX, W, H,
                                d_top_taps, top_K, (const Cand*)ws.cand2.p, (const int*)ws.counters2.p, WW, masks_top,
