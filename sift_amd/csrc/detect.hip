@@ -748,7 +748,7 @@ void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
 
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table) {
     ProfScope ps(ctx, SIFT_HIP_K_ORIENT, ws.stream);
-    hipLaunchKernelGGL(orient_kernel, dim3(256 * 12), dim3(64), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, d_lc,
+    hipLaunchKernelGGL(orient_kernel, dim3(256 * 10), dim3(64), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, d_lc,
                        d_table, (const Cand*)ws.cand.p, (const int*)ws.counters.p, (unsigned long long*)ws.cand_mask.p,
                        (float*)ws.cand_mm.p);
 }
