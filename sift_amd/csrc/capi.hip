@@ -646,6 +646,10 @@ int sift_hip_extract(sift_hip_ctx* ctx, const float* img, int w, int h, int chan
     *n = 0;
     const size_t px = (size_t)w * h;
     int rc;
+    {
+        sift_hip_params checked;  // reject bad parameters and sizes before touching the image
+        if ((rc = checked_params(params, w, h, &checked))) return rc;
+    }
     if ((rc = ensure(ctx, ctx->in_img, px * 4))) return rc;
     if (channels == 3) {
         if ((rc = ensure(ctx, ctx->in_rgb, px * 12))) return rc;
@@ -675,6 +679,10 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
         return SIFT_HIP_ERR_ARG;
     const size_t px = (size_t)w * h;
     int rc;
+    {
+        sift_hip_params checked;
+        if ((rc = checked_params(params, w, h, &checked))) return rc;
+    }
     if ((rc = ensure(ctx, ctx->in_img, px * 4))) return rc;
     if ((rc = ensure(ctx, ctx->frame2, px * 4))) return rc;
     float* slot[2] = {(float*)ctx->in_img.p, (float*)ctx->frame2.p};
@@ -762,7 +770,9 @@ int sift_hip_octave_levels(sift_hip_ctx* ctx, const float* gray, int w, int h, c
     if (bad_ctx(ctx) || !gray || w < 2 || h < 2 || octave < 0 || !ow || !oh) return SIFT_HIP_ERR_ARG;
     sift_hip_params prm;
     if (params) prm = *params; else sift_hip_default_params(&prm);
-    if (prm.intvls < 1 || prm.intvls > 8) return SIFT_HIP_ERR_ARG;
+    if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || prm.octaves > 24 || !(prm.sigma0 > 0.f))
+        return SIFT_HIP_ERR_ARG;
+    if ((long long)w * h * 4 >= (1ll << 31)) return SIFT_HIP_ERR_LIMIT;
     if (prm.octaves > 0 && prm.octaves <= octave) prm.octaves = octave + 1;
     int rc = build_plan(ctx, w, h, prm);
     if (rc) return rc;

@@ -346,3 +346,36 @@ def test_extract_subpixel_with_other_interval_count(sift, oracle):
     assert len(fo) > 10
     check_features(f, hist, fo, ho)
     assert np.array_equal(bits(sift.last_offsets(len(f))), bits(so))
+
+
+def test_extract_argument_errors(sift):
+    import ctypes as C
+
+    img = sift_amd.blob_image(64, 64, seed=1)
+    out = np.zeros(16, sift_amd.FEAT_DTYPE)
+    n = C.c_int(0)
+
+    def call(prm, w=64, h=64, ch=1, img_p=img.ctypes.data, out_p=out.ctypes.data, cap=16, n_p=C.byref(n)):
+        c = prm._c()
+        return sift.lib.sift_hip_extract(sift.h, C.c_void_p(img_p), w, h, ch, C.byref(c), C.c_void_p(out_p), cap, n_p, None)
+
+    E = sift_amd.capi
+    assert call(SiftParams(intvls=0)) == E.ERR_ARG
+    assert call(SiftParams(intvls=9)) == E.ERR_ARG
+    assert call(SiftParams(octaves=25)) == E.ERR_ARG
+    assert call(SiftParams(octaves=-1)) == E.ERR_ARG
+    assert call(SiftParams(sigma0=0.0)) == E.ERR_ARG
+    assert call(SiftParams(), ch=2) == E.ERR_ARG
+    assert call(SiftParams(), w=1) == E.ERR_ARG
+    assert call(SiftParams(), img_p=0) == E.ERR_ARG
+    assert call(SiftParams(), out_p=0) == E.ERR_ARG
+    assert call(SiftParams(), cap=-1) == E.ERR_ARG
+    assert call(SiftParams(), n_p=None) == E.ERR_ARG
+    # octave 0 of a 23171^2 image would not fit the 32-bit pixel index of a level; checked before any work
+    assert call(SiftParams(), w=23171, h=23171) == E.ERR_LIMIT
+    # the context is still usable afterwards
+    f, _ = sift.extract(img)
+    assert sift.lib.sift_hip_strerror(E.ERR_LIMIT).decode() != ""
+    # cap = 0 with no output buffer: the count comes back with ERR_NOSPC (or OK when there is nothing)
+    rc = call(SiftParams(), out_p=0, cap=0)
+    assert rc in (E.OK, E.ERR_NOSPC) and n.value == len(f)
