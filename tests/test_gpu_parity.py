@@ -155,7 +155,8 @@ def test_extract_batch_equals_single_frames(sift):
         assert np.array_equal(out[i, : n[i]]["x"], f["x"])
 
 
-@pytest.mark.parametrize("nq,nr", [(1, 1), (5, 2), (64, 64), (257, 129), (1000, 3000), (300, 1)])
+@pytest.mark.parametrize("nq,nr", [(1, 1), (5, 2), (64, 64), (257, 129), (1000, 3000), (300, 1), (10, 0), (0, 10),
+                                   (2049, 20001)])
 @pytest.mark.parametrize("form", [0, 1])
 def test_match_bit_exact(sift, oracle, nq, nr, form):
     q, r = sift_amd.planted_descriptors(nq, nr, vmax=255, plant=0.2)
