@@ -1,5 +1,6 @@
-// 4x4x8 descriptor for gfx950: one wavefront per feature, the 128-bin histogram
-// in LDS, samples of the (2R+1)^2 window spread over the 64 lanes.
+// 4x4x8 descriptor for gfx950: one workgroup (64...1024 threads, chosen per octave
+// from the window size) per feature, the 128-bin histogram in LDS, the samples of
+// the (2R+1)^2 window that can fall into the rotated 4x4 grid spread over its threads.
 //
 // Arithmetic follows Sift::descr_hist / interp_hist_entry / hist_to_descr
 // (Sift.cpp:299-421) expression by expression, including that the orientation in

@@ -1,8 +1,11 @@
 // Keypoint detection for one octave on gfx950:
 //   detect_tile   3x3x3 extremum + contrast + edge test on LDS-staged DoG tiles
 //                 (all layers); wavefront ballots become 64-pixel mask words
+//   top_check     the top layer's comparison with the layer above it, whose
+//                 Gaussian level is evaluated only at the pixels that need it
 //   scan_rows     exclusive prefix sum of the per-row counts (one workgroup)
 //   expand_rows   mask words -> ordered candidate list (wave prefix sums)
+//   refine        optional sub-pixel stage (interp_extremum), one lane per candidate
 //   orient        36-bin orientation histogram, one wavefront per candidate
 //   emit          candidates x firing bins -> feature records, in reference order
 //
