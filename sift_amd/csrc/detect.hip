@@ -466,14 +466,15 @@ __device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
 // pixels:
 //   A  all lanes evaluate magnitude and bin of their pixels (strided, coalesced)
 //   B  a stable counting sort by bin: lane l owns the ORI_RUN consecutive pixels
-//      16l..16l+15, counts them per bin with LDS atomics, lane b turns row b of
+//      RUN*l..RUN*l+RUN-1, counts them per bin with LDS atomics, lane b turns row b of
 //      the (bin x lane) count matrix into running offsets, and the pixels are
 //      scattered to (bin, lane, rank) order -- window order within each bin
 //   C  lane b adds the values of bin b front to back.
 // Lane b touches only its own ~1/36 of the pixels instead of testing every pixel
 // against its bin number.
-constexpr int ORI_CH = 1024;
-constexpr int ORI_RUN = 16;
+constexpr int ORI_CH = 512;                 // pixels per pass (1024 and 2048 measured slower: fewer resident waves)
+constexpr int ORI_RUN = ORI_CH / 64;       // consecutive pixels a lane owns in the sort
+constexpr int ORI_BW = (ORI_RUN / 4) | 1;     // dwords per lane run of bin bytes (odd: conflict-free)
 constexpr int AU = 4;
 constexpr int ORI_ROW = 33;  // dwords per count-matrix row: 32 lane pairs (two u16 each) + 1 pad
 
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
                                                     const float* __restrict__ table, const Cand* __restrict__ cand,
                                                     const int* __restrict__ counters,
                                                     unsigned long long* __restrict__ cmask, float* __restrict__ cmm) {
-    __shared__ float s_val[ORI_CH + ORI_CH / ORI_RUN];                      // pixel e at e + e/16
-    __shared__ unsigned s_binw[64 * 5];                                     // bin of pixel e: byte (e/16)*20 + e%16
+    __shared__ float s_val[ORI_CH + ORI_CH / ORI_RUN];                      // pixel e at e + e/RUN
+    __shared__ unsigned s_binw[64 * ORI_BW];                                // bin of pixel e: byte (e/RUN)*4*BW + e%RUN
     __shared__ __attribute__((aligned(16))) unsigned s_cnt[37 * ORI_ROW + 59];  // 1280 dwords
     __shared__ float s_sorted[ORI_CH];
     __shared__ int s_base[36];
@@ -557,8 +558,8 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
                         const float th = fast_atan2f_deg(dy, dx);
                         mag = mag * wgt_i[u];
                         mag = mag * wgt_j[u];
-                        s_val[e + (e >> 4)] = mag;
-                        s_bin[(e >> 4) * 20 + (e & 15)] = (unsigned char)angle_bin(th);  // 36 == "one past the end": dropped
+                        s_val[e + e / ORI_RUN] = mag;
+                        s_bin[(e / ORI_RUN) * (4 * ORI_BW) + (e % ORI_RUN)] = (unsigned char)angle_bin(th);  // 36 == "one past the end": dropped
                     }
                 }
             }
@@ -569,9 +570,9 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
             }
             __syncthreads();
             // ---- B1: per-(bin, lane) counts of the lane's run of 16 pixels
-            unsigned bw[4];
+            unsigned bw[ORI_RUN / 4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) bw[i] = s_binw[lane * 5 + i];
+            for (int i = 0; i < ORI_RUN / 4; i++) bw[i] = s_binw[lane * ORI_BW + i];
             const int run0 = lane * ORI_RUN;
 #pragma unroll
             for (int t = 0; t < ORI_RUN; t++) {
@@ -751,7 +752,10 @@ void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
 
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table) {
     ProfScope ps(ctx, SIFT_HIP_K_ORIENT, ws.stream);
-    hipLaunchKernelGGL(orient_kernel, dim3(256 * 10), dim3(64), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, d_lc,
+    // persistent one-wave workgroups, as many as are resident at once (LDS-limited)
+    constexpr int lds_bytes = (ORI_CH + ORI_CH / ORI_RUN) * 4 + 64 * ORI_BW * 4 + (37 * ORI_ROW + 59) * 4 + ORI_CH * 4 + 36 * 4;
+    constexpr int per_cu = (160 * 1024 / lds_bytes) < 32 ? (160 * 1024 / lds_bytes) : 32;
+    hipLaunchKernelGGL(orient_kernel, dim3(256 * per_cu), dim3(64), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, d_lc,
                        d_table, (const Cand*)ws.cand.p, (const int*)ws.counters.p, (unsigned long long*)ws.cand_mask.p,
                        (float*)ws.cand_mm.p);
 }
