@@ -380,3 +380,52 @@ def test_extract_argument_errors(sift):
     # cap = 0 with no output buffer: the count comes back with ERR_NOSPC (or OK when there is nothing)
     rc = call(SiftParams(), out_p=0, cap=0)
     assert rc in (E.OK, E.ERR_NOSPC) and n.value == len(f)
+
+
+# ---- randomised shapes (fixed seeds): tails of every tiling at once ---------------------
+def test_match_random_shapes(sift, oracle):
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        nq = int(rng.integers(1, 700))
+        nr = int(rng.integers(1, 2600))
+        vmax = int(rng.choice([3, 102, 255]))
+        q, r = sift_amd.planted_descriptors(nq, nr, seed_q=10 + case, seed_r=50 + case, vmax=vmax, plant=0.1)
+        if case % 5 == 0 and nr > 4:  # exact duplicates among the references: ties on the winner
+            r[nr // 2] = r[1]
+            r[nr - 1] = r[1]
+        form = case & 1
+        th = float(rng.choice([0.3, 0.5, 0.8, 1.0]))
+        best, d1, d2 = sift.match_u8(q, r, th, form)
+        bo, d1o, d2o = oracle.match_u8(q, r, th, form)
+        assert np.array_equal(d1, d1o) and np.array_equal(d2, d2o) and np.array_equal(best, bo), (case, nq, nr)
+
+
+def test_extract_random_shapes(sift, oracle):
+    rng = np.random.default_rng(77)
+    total = 0
+    for case in range(8):
+        w = int(rng.integers(70, 330))
+        h = int(rng.integers(70, 260))
+        img = sift_amd.blob_image(w, h, seed=100 + case)
+        prm = SiftParams(octaves=int(rng.integers(0, 4)))
+        f, hist = sift.extract(img, prm, want_hist=True)
+        fo, ho = oracle.extract(img, octaves=prm.octaves)
+        assert len(f) == len(fo), (case, w, h)
+        if len(fo):
+            check_features(f, hist, fo, ho)
+        total += len(fo)
+    assert total > 300
+
+
+def test_blur_and_resample_random_shapes(sift, oracle):
+    rng = np.random.default_rng(5)
+    for case in range(12):
+        w = int(rng.integers(1, 700))
+        h = int(rng.integers(1, 200))
+        p = float(rng.uniform(0.6, 12.0))
+        img = rng.random((h, w), dtype=np.float32)
+        assert np.array_equal(bits(sift.gau_blur(img, p)), bits(oracle.gau_blur(img, p))), (case, w, h, p)
+        if w >= 2 and h >= 2:
+            ratio = float(rng.choice([2.0, 1.0, 0.5, 0.25]))
+            if int(w * ratio) >= 1 and int(h * ratio) >= 1:
+                assert np.array_equal(bits(sift.first(img, ratio)), bits(oracle.first(img, ratio))), (case, w, h, ratio)
