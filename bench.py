@@ -193,6 +193,28 @@ def main():
         for _ in range(3):
             ctx.extract(frame.reshape(H, W), prm, cap=cap)
         extras["host_buffer_ms_per_frame"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        # the library's batch entry point on 8 copies of the frame: frame f's kernels are enqueued
+        # before frame f-1's features are fetched, so the device does not wait for the host
+        import ctypes as C
+        nb = 8
+        d_batch = d_frame.reshape(1, -1).repeat(nb, 1).contiguous()
+        bout = np.zeros((nb, cap), sift_amd.FEAT_DTYPE)
+        bn = np.zeros(nb, np.int32)
+        cprm = prm._c()
+
+        def run_batch():
+            rc = ctx.lib.sift_hip_extract_batch_dev(ctx.h, C.c_void_p(d_batch.data_ptr()), W, H, nb, C.byref(cprm),
+                                                    C.c_void_p(bout.ctypes.data), cap, bn.ctypes.data_as(C.POINTER(C.c_int)))
+            if rc != 0:
+                raise RuntimeError("sift_hip_extract_batch_dev failed: %d" % rc)
+
+        run_batch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_batch()
+        torch.cuda.synchronize()
+        extras["batch_ms_per_frame"] = round((time.perf_counter() - t0) / nb * 1e3, 3)
+        del d_batch
         if args.blur_mode == 0:
             # fp32-FMA blur: not the reference's arithmetic (a fraction of a percent of keypoints change)
             fast = SiftParams(octaves=args.octaves, blur_mode=1)

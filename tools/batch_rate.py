@@ -21,12 +21,13 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--octaves", type=int, default=4)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--cap", type=int, default=1 << 14, help="feature capacity per frame")
 a = ap.parse_args()
 ctx = sift_amd.SiftHip(0)
 base = [sift_amd.blob_image(a.width, a.height, seed=40 + k) for k in range(4)]
 frames = np.stack([base[k % 4] for k in range(a.frames)])
 d = torch.from_numpy(frames).cuda()
-cap = 1 << 14
+cap = a.cap
 out = np.zeros((a.frames, cap), sift_amd.FEAT_DTYPE)
 n = np.zeros(a.frames, np.int32)
 prm = SiftParams(octaves=a.octaves)._c()
