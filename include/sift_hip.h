@@ -9,9 +9,11 @@
  * context owns every device buffer.  No entry point throws; all return
  * SIFT_HIP_OK (0) or a negative sift_hip_status.
  *
- * Threading: a context is bound to one device and one HIP stream and is not
- * thread-safe.  Use one context per GPU (or per stream); distinct contexts may
- * be driven concurrently from different threads.
+ * Threading: a context is bound to one device and is not thread-safe.  Use one
+ * context per GPU; distinct contexts may be driven concurrently from different
+ * threads.  A lone context overlaps the octaves of a frame on two HIP streams; while
+ * more than one context is alive on a device each keeps to its main stream (stream
+ * pairs ordered by device-side event waits would outnumber the hardware queues).
  */
 #ifndef SIFT_HIP_H
 #define SIFT_HIP_H

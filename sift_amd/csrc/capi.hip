@@ -16,6 +16,15 @@
 
 using namespace sifthip;
 
+// Contexts alive per device.  The two-stream extract orders its streams with
+// device-side event waits; when several contexts do that on one device at once,
+// their streams outnumber the hardware queues (4), share them, and the waits can
+// form a cycle that never resolves (observed: two contexts extracting from two
+// threads hang).  With more than one context alive on a device every extract
+// therefore stays on its context's main stream.
+#include <atomic>
+static std::atomic<int> g_live_contexts[64];
+
 namespace sifthip {
 
 bool hip_ok(sift_hip_ctx* ctx, hipError_t e, const char* what) {
@@ -303,7 +312,7 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         return SIFT_HIP_ERR_HIP;
     hipEventRecord(ctx->ev_start, ctx->stream);
     const float thr = (float)((double)prm.dx_thr / 2.0);
-    const bool serial = ctx->profiling || ctx->force_serial || noct < 2;
+    const bool serial = ctx->profiling || ctx->force_serial || noct < 2 || g_live_contexts[ctx->device & 63].load() > 1;
     // Streams: octave 0 (75 % of the pixels) on the context's stream, the smaller
     // octaves one after another on a second, lower-priority stream that fills the
     // gaps.  No octave waits for another; the context's stream is ordered after
@@ -547,6 +556,7 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
         sift_hip_destroy(ctx);
         return SIFT_HIP_ERR_HIP;
     }
+    g_live_contexts[device & 63].fetch_add(1);
     *out = ctx;
     return SIFT_HIP_OK;
 }
@@ -581,6 +591,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     for (auto& e : ctx->free_events) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    g_live_contexts[ctx->device & 63].fetch_sub(1);
     delete ctx;
     return SIFT_HIP_OK;
 }

@@ -429,3 +429,26 @@ def test_blur_and_resample_random_shapes(sift, oracle):
             ratio = float(rng.choice([2.0, 1.0, 0.5, 0.25]))
             if int(w * ratio) >= 1 and int(h * ratio) >= 1:
                 assert np.array_equal(bits(sift.first(img, ratio)), bits(oracle.first(img, ratio))), (case, w, h, ratio)
+
+
+def test_two_contexts_extract_concurrently(sift):
+    """Two contexts on one device driven from two threads: each falls back to its main
+    stream (their event-ordered stream pairs would outnumber the hardware queues and
+    can wait on each other forever) and both give the single-context result."""
+    import threading
+
+    img = sift_amd.blob_image(640, 480, seed=8)
+    want, _ = sift.extract(img)
+    other = sift_amd.SiftHip(0)
+    got = {}
+
+    def work(name, ctx):
+        for _ in range(6):
+            got[name], _ = ctx.extract(img)
+
+    ths = [threading.Thread(target=work, args=("a", sift)), threading.Thread(target=work, args=("b", other))]
+    [t.start() for t in ths]
+    [t.join(timeout=100) for t in ths]
+    assert not any(t.is_alive() for t in ths), "concurrent contexts hang"
+    other.close()
+    assert got["a"].tobytes() == want.tobytes() and got["b"].tobytes() == want.tobytes()
