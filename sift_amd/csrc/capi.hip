@@ -323,7 +323,12 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         return ctx->lanes[std::min(oi, nside)].stream;
     };
     for (int s = 1; s <= nside && s < noct && !serial; s++) hipStreamWaitEvent(ctx->lanes[s].stream, ctx->ev_start, 0);
-    for (int oi = 0; oi < noct; oi++) {
+    // Host launch order: octave 0's pyramid first (long kernels that keep the main stream busy),
+    // then all of octave 1 so that the side stream starts early, then the rest of octave 0,
+    // then the remaining octaves (within run-to-run noise of launching octave by octave on
+    // this host, but it does not depend on the host launching faster than octave 0 runs).
+    // Each octave's own launches stay in order on its stream.
+    auto enqueue_part = [&](int oi, int part) -> int {  // part 0 = pyramid, 1 = detect ... describe
         OctWs& ws = ctx->lanes[oi];
         const hipStream_t own = ws.stream;
         const hipStream_t st = stream_of(oi);
@@ -337,8 +342,10 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         // (a workgroup sweeps K+2 rows of K+2 inputs per candidate: beyond ~1000 taps, i.e. in
         // octaves of a few thousand pixels, building the level is cheaper)
         const bool lazy = !prm.subpixel && !ctx->full_top_level && top_K <= 1024;
-        rc = run_octave_pyramid(ctx, ws, st, d_gray, oi, lazy ? 1 : 0);
-        if (!rc) {
+        int r = SIFT_HIP_OK;
+        if (part == 0) {
+            r = run_octave_pyramid(ctx, ws, st, d_gray, oi, lazy ? 1 : 0);
+        } else {
             const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
             launch_detect(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap,
                           lazy ? (const float*)ctx->table.p + oc.tap_off[prm.intvls + 2] : nullptr, top_K);
@@ -356,7 +363,17 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
                          want_hist ? (float*)ws.hist.p : nullptr, max_window);
         }
         ws.stream = own;
-        if (rc) return rc;
+        return r;
+    };
+    if ((rc = enqueue_part(0, 0))) return rc;
+    if (noct > 1) {
+        if ((rc = enqueue_part(1, 0))) return rc;
+        if ((rc = enqueue_part(1, 1))) return rc;
+    }
+    if ((rc = enqueue_part(0, 1))) return rc;
+    for (int oi = 2; oi < noct; oi++) {
+        if ((rc = enqueue_part(oi, 0))) return rc;
+        if ((rc = enqueue_part(oi, 1))) return rc;
     }
     for (int s = 1; s <= nside && s < noct && !serial; s++) {
         hipEventRecord(ctx->lanes[s].ev_done, ctx->lanes[s].stream);
