@@ -249,19 +249,21 @@ size_t Stitching::Match(float matchTh) {
 }
 
 #ifdef SIFT_AMD_WITH_CONSUMERS
-// The reference's own RANSAC and blender (ransac/xform.hpp:4-6, stitch/Blend.hpp:15).
-extern std::vector<float> ransac_xform(Feature* features, int n, int m, float p_badxform, float err_tol,
-                                       Feature*** inliers, int& n_in);
+// The reference's own blender (stitch/Blend.hpp:15).
 void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::vector<float>& HomogMat,
               const Feature* const* RANSAC_feat, int RANSAC_num);
 #endif
 
+Stitching::~Stitching() { delete[] RANSAC_feat; }
+
 void Stitching::Check(float matchTh) {
     Match(matchTh);
+    // Sift.cpp:681-684
+    delete[] RANSAC_feat;
+    RANSAC_feat = nullptr;
+    RANSAC_num = 0;
+    HomogMat = ransac_xform(feat2, (int)feat2_Count, 4, 0.005f, 3.f, &RANSAC_feat, RANSAC_num);
 #ifdef SIFT_AMD_WITH_CONSUMERS
-    Feature** RANSAC_feat = nullptr;
-    int RANSAC_num = 0;
-    const std::vector<float> HomogMat = ransac_xform(feat2, (int)feat2_Count, 4, 0.005f, 3.f, &RANSAC_feat, RANSAC_num);
     ImgRaw dst;
     blen2img(img1, img2, dst, HomogMat, RANSAC_feat, RANSAC_num);
 #endif

@@ -10,6 +10,7 @@
 #include "Imgraw.hpp"
 #include "imagedata.hpp"
 #include "imglib.hpp"
+#include "xform.hpp"
 
 #define SIFT_INTVLS 3
 #define SIFT_INTVLS_DIFF 3
@@ -76,13 +77,22 @@ public:
 class Stitching {
 public:
     Stitching(const Sift& desc1, const Sift& desc2);
-    // Sift.cpp:669-702.  Matching (the part on the GPU path) always runs:
-    // queries = image-2 features, references = image-1 features, result in
-    // feat2[i].fwd_match.  RANSAC and blending are the reference's own code; they
-    // are called only when this file is built with SIFT_AMD_WITH_CONSUMERS.
+    ~Stitching();
+    Stitching(const Stitching&) = delete;
+    Stitching& operator=(const Stitching&) = delete;
+    // Sift.cpp:669-702.  Matching (the part on the GPU path): queries = image-2
+    // features, references = image-1 features, result in feat2[i].fwd_match.
+    // Then ransac_xform (xform.hpp) over those matches; its results stay in the
+    // three members below, which the reference keeps as locals and prints.
+    // Blending is the reference's own code, called only when this file is built
+    // with SIFT_AMD_WITH_CONSUMERS.
     void Check(float matchTh = NN_SQ_DIST_RATIO_THR);
     // The matching step of Check() alone; returns the number of accepted matches.
     size_t Match(float matchTh = NN_SQ_DIST_RATIO_THR);
+
+    std::vector<float> HomogMat;     // image 2 -> image 1, row-major 3x3; empty if RANSAC found no model
+    Feature** RANSAC_feat = nullptr; // consensus features (of image 2); owned
+    int RANSAC_num = 0;
 
 private:
     Feature *feat1, *feat2;

@@ -5,6 +5,8 @@
 // out.bin: int32 n1, n2; n1 + n2 records {float size; int kai; float sigmaOCT;
 //          int x, y; float mm; int sita; uint8 descr[128]}; then n2 int32 match
 //          indices into image 1's features (-1 = none)
+// stdout: one JSON line with counts, the RANSAC homography (image 2 -> image 1)
+//          and the indices of its consensus features in image 2
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +55,7 @@ int main(int argc, char** argv) {
         Sift fea2(img2);
         fea2.pyramid();
         Stitching match(fea1, fea2);
+        sift_amd::ransac_seed() = 1234;  // reproducible sample stream for the checker
         match.Check(th);
         FILE* o = fopen(argv[2], "wb");
         if (!o) { perror("open output"); return 2; }
@@ -82,8 +85,12 @@ int main(int argc, char** argv) {
             sy += fea3.FeatStart[i].img_pt.y;
         }
         printf("{\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
-               "\"sub_sum_y\": %.6f}\n",
-               fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy);
+               "\"sub_sum_y\": %.6f, \"ransac_num\": %d, \"homog\": [",
+               fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy, match.RANSAC_num);
+        for (size_t i = 0; i < match.HomogMat.size(); i++) printf("%s%.9g", i ? ", " : "", match.HomogMat[i]);
+        printf("], \"ransac_feat\": [");
+        for (int i = 0; i < match.RANSAC_num; i++) printf("%s%d", i ? ", " : "", (int)(match.RANSAC_feat[i] - fea2.FeatStart));
+        printf("]}\n");
     } catch (const std::exception& e) {
         fprintf(stderr, "selftest failed: %s\n", e.what());
         return 1;

@@ -9,6 +9,10 @@ import pytest
 
 import sift_amd
 
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import ransac_oracle  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "sift_amd", "host", "selftest")
@@ -48,6 +52,23 @@ def test_cpp_classes_equal_c_abi_and_oracle(tmp_path, sift, oracle):
     bo, _, _ = oracle.match_u8(fb["descr"], fa["descr"], 0.5, 0)
     assert np.array_equal(m, bo)
     assert info["matched"] == int((bo >= 0).sum()) > 20
+    # ransac_xform over those matches (Sift.cpp:684): same libc random stream as the numpy
+    # restatement -> same consensus; image 2 is image 1 moved 8 px, so H is that translation
+    sel = np.nonzero(m >= 0)[0]
+    pts = np.stack([f2["x"][sel] / f2["size"][sel], f2["y"][sel] / f2["size"][sel]], axis=1).astype(np.float32)
+    mp = f1[m[sel]]
+    mpts = np.stack([mp["x"] / mp["size"], mp["y"] / mp["size"]], axis=1).astype(np.float32)
+    Ho, fin, in_min = ransac_oracle.ransac_xform(pts, mpts, 4, 0.005, 3.0, 1234)
+    assert Ho is not None and info["ransac_num"] == len(fin) >= in_min
+    assert info["ransac_feat"] == [int(v) for v in sel[fin]]
+    H = np.array(info["homog"])
+    np.testing.assert_allclose(H, Ho, rtol=1e-3, atol=1e-5)
+    cx, cy = 128.0, 96.0
+    den = H[6] * cx + H[7] * cy + H[8]
+    moved = np.array([(H[0] * cx + H[1] * cy + H[2]) / den - cx, (H[3] * cx + H[4] * cy + H[5]) / den - cy])
+    assert abs(abs(moved[0]) - 8.0) < 1.0 and abs(moved[1]) < 1.0
+    err = ransac_oracle.xfer_err(H.astype(np.float32), pts[fin], mpts[fin])
+    assert err.max() <= 3.0
     # options().subpixel = 1: Feature::img_pt = (x + xc, y + xr) / size (matrix.hpp:188-189)
     fs, _ = sift.extract(a, sift_amd.SiftParams(subpixel=1))
     sub = sift.last_offsets(len(fs))
