@@ -156,6 +156,33 @@ int sift_hip_match_u8_sharded(sift_hip_ctx* ctx, void* comm, int nranks, const u
                               const uint8_t* d_r_local, int nr_local, float ratio, int ratio_form, int32_t* d_best,
                               int32_t* d_d1, int32_t* d_d2);
 
+/* ---- RANSAC homography over the matches: replaces ransac_xform, ---------------------
+ * Sift/ransac/xform.cpp:37-168 (its call site: Stitching::Check, Sift.cpp:684) --------
+ * q_feats[0..nq): image-2 features (the matcher's queries), r_feats[0..nr): image-1
+ * features, best[i]: the matcher's output for query i (index into r_feats, or -1).
+ * Estimates the homography taking a matched query's source-image position
+ * (x / size, y / size) to its match's, from samples of m pairs (4 <= m <= 8):
+ * every sample is fitted (lsq_homog, xform.cpp:177-219, here a QR solve in double
+ * instead of OpenCV's SVD) and every model's consensus counted
+ * (find_consensus, xform.cpp:365-395) on the GPU, in batches; the stopping rule,
+ * the minimum consensus (calc_min_inliers, xform.cpp:261-281) and the two final
+ * refits follow the reference.  Samples come from libc's rand() seeded with `seed`
+ * (0: the wall clock, as the reference does at xform.cpp:42).
+ * Outputs (host memory): H9 = row-major 3x3 with H9[8] = 1; inlier_idx (capacity
+ * nq) = query indices of the final consensus in ascending order; *n_in = its size,
+ * or -1 when there are fewer than m matches or no model reached the minimum
+ * consensus (H9 and inlier_idx are then left untouched); *iterations (optional) =
+ * samples the loop consumed.  Blocks until done. */
+int sift_hip_ransac_homog(sift_hip_ctx* ctx, const sift_hip_feat* q_feats, int nq, const sift_hip_feat* r_feats,
+                          int nr, const int32_t* best, int m, float p_badxform, float err_tol, unsigned seed,
+                          float* H9, int32_t* inlier_idx, int32_t* n_in, int32_t* iterations);
+/* The same with q_feats, r_feats and best in device memory (e.g. the buffers
+ * sift_hip_match_u8_dev wrote); the outputs stay host pointers. */
+int sift_hip_ransac_homog_dev(sift_hip_ctx* ctx, const sift_hip_feat* d_q_feats, int nq,
+                              const sift_hip_feat* d_r_feats, int nr, const int32_t* d_best, int m, float p_badxform,
+                              float err_tol, unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in,
+                              int32_t* iterations);
+
 /* ---- measurement ------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; totals are kept per kernel class. */
@@ -172,7 +199,8 @@ enum {
     SIFT_HIP_K_GRAY = 9,
     SIFT_HIP_K_BLUR_ROW_SMALL = 10, /* the blur passes of octaves below 3 Mpixel (fewer outputs per thread) */
     SIFT_HIP_K_BLUR_COL_SMALL = 11,
-    SIFT_HIP_K_COUNT = 12
+    SIFT_HIP_K_RANSAC = 12, /* pair gather, sample fits, consensus counts */
+    SIFT_HIP_K_COUNT = 13
 };
 int sift_hip_profile(sift_hip_ctx* ctx, int enable);
 /* Synchronises, then fills ms[k] = summed kernel time and launches[k] = launch

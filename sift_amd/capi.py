@@ -29,7 +29,7 @@ FEAT_DTYPE = np.dtype(
 assert FEAT_DTYPE.itemsize == 156
 
 KERNEL_CLASSES = ("resample", "blur_row", "blur_col", "detect", "compact", "orient", "emit", "descr", "match", "gray",
-                  "blur_row_small", "blur_col_small")
+                  "blur_row_small", "blur_col_small", "ransac")
 
 OK, ERR_ARG, ERR_NOSPC, ERR_HIP, ERR_NOMEM, ERR_SAME, ERR_NODEVICE, ERR_LIMIT = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -111,6 +111,10 @@ def load_library() -> C.CDLL:
         "sift_hip_match_u8": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_match_u8_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_match_u8_sharded": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+        "sift_hip_ransac_homog": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_uint,
+                                            vp, vp, ip, ip]),
+        "sift_hip_ransac_homog_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float,
+                                                C.c_uint, vp, vp, ip, ip]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
         "sift_hip_kernel_class_name": (C.c_char_p, [C.c_int]),
@@ -294,6 +298,27 @@ class SiftHip:
     def match_u8_dev(self, d_q, nq: int, d_r, nr: int, ratio: float, ratio_form: int, d_best, d_d1=None, d_d2=None):
         self._check(self.lib.sift_hip_match_u8_dev(self.h, _ptr(d_q), nq, _ptr(d_r), nr, ratio, ratio_form,
                                                    _ptr(d_best), _ptr(d_d1), _ptr(d_d2)))
+
+    # ---- RANSAC homography over the matches ------------------------------------------
+    def ransac_homog(self, q_feats: np.ndarray, r_feats: np.ndarray, best: np.ndarray, m: int = 4,
+                     p_badxform: float = 0.005, err_tol: float = 3.0, seed: int = 0):
+        """ransac_xform (ransac/xform.cpp:37-168) with its call site's arguments as defaults
+        (Sift.cpp:684).  Returns (H 3x3 float32 or None, query indices of the consensus, samples used)."""
+        q_feats = np.ascontiguousarray(q_feats, FEAT_DTYPE)
+        r_feats = np.ascontiguousarray(r_feats, FEAT_DTYPE)
+        best = np.ascontiguousarray(best, np.int32)
+        nq, nr = len(q_feats), len(r_feats)
+        assert len(best) == nq
+        H = np.zeros(9, np.float32)
+        idx = np.full(max(nq, 1), -1, np.int32)
+        n_in = C.c_int(0)
+        iters = C.c_int(0)
+        self._check(self.lib.sift_hip_ransac_homog(self.h, _ptr(q_feats), nq, _ptr(r_feats), nr, _ptr(best), m,
+                                                   p_badxform, err_tol, seed, _ptr(H), _ptr(idx), C.byref(n_in),
+                                                   C.byref(iters)))
+        if n_in.value < 0:
+            return None, idx[:0], iters.value
+        return H.reshape(3, 3), idx[:n_in.value].copy(), iters.value
 
     # ---- measurement ----------------------------------------------------------------
     def profile(self, enable: bool):

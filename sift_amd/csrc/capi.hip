@@ -595,7 +595,9 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     }
     DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->table, &ctx->layer_consts,
                       &ctx->gcounters, &ctx->gcounters_alt, &ctx->gathered, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
-                      &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all};
+                      &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all,
+                      &ctx->ransac.blk, &ctx->ransac.pairs, &ctx->ransac.src, &ctx->ransac.flags, &ctx->ransac.samples,
+                      &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
@@ -909,6 +911,43 @@ int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t
     return check_async(ctx, "match");
 }
 
+static int ransac_args_bad(sift_hip_ctx* ctx, const void* q, int nq, const void* r, int nr, const void* best, int m,
+                           float p_badxform, float err_tol, const int32_t* n_in) {
+    if (bad_ctx(ctx) || nq < 0 || nr < 0 || !n_in || (nq > 0 && (!q || !best)) || (nr > 0 && !r)) return 1;
+    return m < 4 || m > 8 || !(p_badxform > 0.f) || !(p_badxform < 1.f) || !(err_tol >= 0.f);
+}
+
+int sift_hip_ransac_homog_dev(sift_hip_ctx* ctx, const sift_hip_feat* d_q_feats, int nq,
+                              const sift_hip_feat* d_r_feats, int nr, const int32_t* d_best, int m, float p_badxform,
+                              float err_tol, unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in,
+                              int32_t* iterations) {
+    if (ransac_args_bad(ctx, d_q_feats, nq, d_r_feats, nr, d_best, m, p_badxform, err_tol, n_in))
+        return SIFT_HIP_ERR_ARG;
+    const int rc = run_ransac(ctx, d_q_feats, nq, d_r_feats, nr, d_best, m, p_badxform, err_tol, seed, H9,
+                              inlier_idx, n_in, iterations);
+    if (rc) return rc;
+    return check_async(ctx, "ransac");
+}
+
+int sift_hip_ransac_homog(sift_hip_ctx* ctx, const sift_hip_feat* q_feats, int nq, const sift_hip_feat* r_feats,
+                          int nr, const int32_t* best, int m, float p_badxform, float err_tol, unsigned seed,
+                          float* H9, int32_t* inlier_idx, int32_t* n_in, int32_t* iterations) {
+    if (ransac_args_bad(ctx, q_feats, nq, r_feats, nr, best, m, p_badxform, err_tol, n_in)) return SIFT_HIP_ERR_ARG;
+    sifthip::RansacWs& ws = ctx->ransac;
+    int rc;
+    if ((rc = ensure(ctx, ws.qf, (size_t)std::max(nq, 1) * sizeof(sift_hip_feat)))) return rc;
+    if ((rc = ensure(ctx, ws.rf, (size_t)std::max(nr, 1) * sizeof(sift_hip_feat)))) return rc;
+    if ((rc = ensure(ctx, ws.best, (size_t)std::max(nq, 1) * 4))) return rc;
+    if (nq > 0) {
+        hipMemcpyAsync(ws.qf.p, q_feats, (size_t)nq * sizeof(sift_hip_feat), hipMemcpyHostToDevice, ctx->stream);
+        hipMemcpyAsync(ws.best.p, best, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (nr > 0) hipMemcpyAsync(ws.rf.p, r_feats, (size_t)nr * sizeof(sift_hip_feat), hipMemcpyHostToDevice, ctx->stream);
+    return sift_hip_ransac_homog_dev(ctx, (const sift_hip_feat*)ws.qf.p, nq, (const sift_hip_feat*)ws.rf.p, nr,
+                                     (const int32_t*)ws.best.p, m, p_badxform, err_tol, seed, H9, inlier_idx, n_in,
+                                     iterations);
+}
+
 int sift_hip_last_offsets(sift_hip_ctx* ctx, float* xyz, int cap) {
     if (!ctx || cap < 0 || (cap > 0 && !xyz)) return SIFT_HIP_ERR_ARG;
     const int n = (int)std::min<size_t>(ctx->h_sub.size() / 3, (size_t)cap);
@@ -946,7 +985,7 @@ int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset
 const char* sift_hip_kernel_class_name(int k) {
     static const char* names[SIFT_HIP_K_COUNT] = {"resample", "blur_row", "blur_col", "detect", "compact", "orient",
                                                   "emit",     "descr",    "match",    "gray",   "blur_row_small",
-                                                  "blur_col_small"};
+                                                  "blur_col_small", "ransac"};
     return (k >= 0 && k < SIFT_HIP_K_COUNT) ? names[k] : "?";
 }
 

@@ -12,6 +12,9 @@
 #pragma once
 #include <math.h>
 
+#include <algorithm>
+#include <vector>
+
 #if defined(__HIPCC__)
 #define SIFT_HD __host__ __device__
 #else
@@ -45,44 +48,60 @@ SIFT_HD inline void dlt_rows(float x, float y, float u, float v, double* r0, dou
 // (|R_kk| <= 1e-12 |R_00|: repeated or collinear sample points).
 SIFT_HD inline int solve_lsq(double* M, int rows, double* h) {
     SIFT_NO_CONTRACT
+    // Every sweep below walks the matrix row by row (it is row-major) and keeps one
+    // running sum per column, so each sum still adds its terms in row order.
     int perm[NCOL];
     for (int c = 0; c < NCOL; c++) perm[c] = c;
     double r00 = 0.0;
     for (int k = 0; k < NCOL; k++) {
-        // pivot: remaining column of largest norm (recomputed, rows are few or the call is rare)
-        int best = k;
-        double bn = -1.0;
-        for (int c = k; c < NCOL; c++) {
-            double s = 0.0;
-            for (int r = k; r < rows; r++) s += M[r * NAUG + c] * M[r * NAUG + c];
-            if (s > bn) { bn = s; best = c; }
+        // pivot: the remaining column of largest norm below row k (first of equals)
+        double cn[NCOL];
+        for (int c = k; c < NCOL; c++) cn[c] = 0.0;
+        for (int r = k; r < rows; r++) {
+            const double* row = M + r * NAUG;
+            for (int c = k; c < NCOL; c++) cn[c] += row[c] * row[c];
         }
+        int best = k;
+        for (int c = k + 1; c < NCOL; c++)
+            if (cn[c] > cn[best]) best = c;
+        const double bn = cn[best];
         if (best != k) {
             for (int r = 0; r < rows; r++) {
-                const double t = M[r * NAUG + k];
-                M[r * NAUG + k] = M[r * NAUG + best];
-                M[r * NAUG + best] = t;
+                double* row = M + r * NAUG;
+                const double t = row[k];
+                row[k] = row[best];
+                row[best] = t;
             }
             const int tp = perm[k]; perm[k] = perm[best]; perm[best] = tp;
         }
         const double norm = sqrt(bn);
         if (k == 0) r00 = norm;
         if (!(norm > 1e-12 * r00) || norm == 0.0) return 0;
-        // Householder vector v = x + sign(x0) |x| e0, stored in place below the diagonal
-        const double x0 = M[k * NAUG + k];
+        // Householder vector v = x - alpha e0 with alpha = -sign(x0) |x|; v's tail stays in column k
+        double* top = M + k * NAUG;
+        const double x0 = top[k];
         const double alpha = x0 >= 0.0 ? -norm : norm;
         const double v0 = x0 - alpha;
         const double vtv = v0 * v0 + (bn - x0 * x0);
         if (vtv > 0.0) {
+            double dot[NAUG];
+            for (int c = k + 1; c < NAUG; c++) dot[c] = v0 * top[c];
+            for (int r = k + 1; r < rows; r++) {
+                const double* row = M + r * NAUG;
+                const double vk = row[k];
+                for (int c = k + 1; c < NAUG; c++) dot[c] += vk * row[c];
+            }
             for (int c = k + 1; c < NAUG; c++) {
-                double dot = v0 * M[k * NAUG + c];
-                for (int r = k + 1; r < rows; r++) dot += M[r * NAUG + k] * M[r * NAUG + c];
-                const double f = 2.0 * dot / vtv;
-                M[k * NAUG + c] -= f * v0;
-                for (int r = k + 1; r < rows; r++) M[r * NAUG + c] -= f * M[r * NAUG + k];
+                dot[c] = 2.0 * dot[c] / vtv;
+                top[c] -= dot[c] * v0;
+            }
+            for (int r = k + 1; r < rows; r++) {
+                double* row = M + r * NAUG;
+                const double vk = row[k];
+                for (int c = k + 1; c < NAUG; c++) row[c] -= dot[c] * vk;
             }
         }
-        M[k * NAUG + k] = alpha;
+        top[k] = alpha;
     }
     double z[NCOL];
     for (int k = NCOL - 1; k >= 0; k--) {
@@ -112,6 +131,72 @@ SIFT_HD inline float homog_xfer_err(const float* T, float x, float y, float u, f
     persp_xform_pt(T, x, y, &px, &py);
     const float dx = px - u, dy = py - v;
     return sqrtf(dx * dx + dy * dy);
+}
+
+// ---- host-side pieces of the RANSAC loop, shared by the CPU and GPU drivers ----------
+// Smallest consensus size for which the chance that a wrong model gathers it is
+// below p_badxform (xform.cpp:246-281).  The reference's helper sums log(i) over
+// [n-m, n] and over [n-i, n], one term more than a binomial coefficient needs, so
+// the factorials here are of n-m-1 and n-i-1, and its i = n term takes log(0) and
+// comes out as exp(-inf) = 0.  Evaluated in double through lgamma.
+inline int ransac_min_inliers(int n, int m, float p_badsupp, float p_badxform) {
+    const double lb = log((double)p_badsupp), lg = log(1.0 - (double)p_badsupp);
+    const double log_nm = lgamma((double)(n - m));  // log((n-m-1)!)
+    std::vector<double> term((size_t)(n > 0 ? n : 0) + 1, 0.0);
+    double sum = 0.0;
+    for (int i = m + 1; i < n; i++) {
+        term[(size_t)i] = exp((double)(i - m) * lb + (double)(n - i + m) * lg + log_nm - lgamma((double)(i - m + 1)) -
+                              lgamma((double)(n - i)));
+        sum += term[(size_t)i];
+        // far beyond the mode (about p_badsupp * n) the terms only shrink: once one has
+        // underflowed to zero the rest are zero too and add nothing
+        if (term[(size_t)i] == 0.0 && (double)(i - m) > 2.0 * (double)p_badsupp * (double)n + 16.0) break;
+    }
+    int j = m + 1;
+    for (; j <= n; j++) {
+        sum -= term[(size_t)j];
+        if (sum < (double)p_badxform) break;
+    }
+    return j;
+}
+
+// Chance that k samples of m all held an outlier when a fraction `frac` of the
+// matches are inliers; pow(float, int) promotes to double in the reference's
+// expression (xform.cpp:61,94) and the result is stored as float.
+inline float ransac_p_bad(float frac, int m, int k) {
+    return (float)pow(1.0 - pow((double)frac, (double)m), (double)k);
+}
+
+// lsq_homog (xform.cpp:177-219) over the pairs idx[0..n) of xyuv (4 floats per
+// pair: x, y -> u, v).  False when n < 4 or the system is rank deficient.
+inline bool fit_pairs(const float* xyuv, const int* idx, int n, float* H9) {
+    if (n < 4) return false;
+    static thread_local std::vector<double> M;  // reused: the final fits take every consensus pair
+    M.resize((size_t)2 * n * NAUG);
+    for (int i = 0; i < n; i++) {
+        const float* p = xyuv + (size_t)idx[i] * 4;
+        dlt_rows(p[0], p[1], p[2], p[3], &M[(size_t)(2 * i) * NAUG], &M[(size_t)(2 * i + 1) * NAUG]);
+    }
+    double h[NCOL];
+    if (!solve_lsq(M.data(), 2 * n, h)) return false;
+    for (int k = 0; k < NCOL; k++) H9[k] = (float)h[k];
+    H9[8] = 1.f;
+    return true;
+}
+
+// Row order of the last fit.  The reference orders the consensus points by x and
+// then by y with an exchange sort (xform.cpp:114-137); row order only moves the
+// solution's rounding, so a stable sort on the same keys stands in for it.
+inline std::vector<int> last_fit_order(const float* xyuv, const std::vector<int>& consensus) {
+    std::vector<int> order = consensus;  // ascending, so the index breaks ties the way a stable sort would
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        const float ya = xyuv[(size_t)a * 4 + 1], yb = xyuv[(size_t)b * 4 + 1];
+        if (ya != yb) return ya < yb;
+        const float xa = xyuv[(size_t)a * 4], xb = xyuv[(size_t)b * 4];
+        if (xa != xb) return xa < xb;
+        return a < b;
+    });
+    return order;
 }
 
 }  // namespace sift_homog

@@ -49,6 +49,10 @@ struct OctWs {
     DevBuf feat_alt, feat_sub_alt;  // second output set: a batch fetches frame f-1 while frame f runs
 };
 
+struct RansacWs {  // device workspace of the RANSAC entry points
+    DevBuf blk, pairs, src, flags, samples, models, counts, qf, rf, best;
+};
+
 struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-183)
     float curr_size;       // 2, 1, 0.5 ...
     float coef;            // 1, 2, 4 ...
@@ -89,6 +93,7 @@ struct sift_hip_ctx {
     int32_t* h_counters_alt = nullptr;  // ... and the other set's
     sifthip::DevBuf gcounters_alt;
     sifthip::DevBuf gathered;  // all ranks' reference descriptors (sharded match)
+    sifthip::RansacWs ransac;
     hipEvent_t ev_frame[2] = {nullptr, nullptr};
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
@@ -153,5 +158,10 @@ void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const f
 // match.hip
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
               int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
+
+// ransac.hip; features and best in device memory, outputs in host memory
+int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_hip_feat* d_r, int nr,
+               const int32_t* d_best, int m, float p_badxform, float err_tol, unsigned seed, float* H9,
+               int32_t* inlier_idx, int32_t* n_in, int32_t* iterations);
 
 }  // namespace sifthip

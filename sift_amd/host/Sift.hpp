@@ -40,6 +40,7 @@ struct Options {
     int subpixel = 0;   // 1 = Lowe refinement (matrix.hpp:140-196), off in the reference
     int blur_mode = 0;  // 0 = exact reference arithmetic
     int ratio_form = 0; // 0 = d0 < d1*th (Sift.cpp:576), 1 = (d0/d1) < th (Sift.cpp:563)
+    int ransac_on_gpu = 1; // Stitching::Check: 1 = sift_hip_ransac_homog, 0 = ransac_xform on the CPU (same result)
 };
 Options& options();
 }  // namespace sift_amd
@@ -82,8 +83,9 @@ public:
     Stitching& operator=(const Stitching&) = delete;
     // Sift.cpp:669-702.  Matching (the part on the GPU path): queries = image-2
     // features, references = image-1 features, result in feat2[i].fwd_match.
-    // Then ransac_xform (xform.hpp) over those matches; its results stay in the
-    // three members below, which the reference keeps as locals and prints.
+    // Then ransac_xform (xform.hpp; on the GPU unless options().ransac_on_gpu is 0)
+    // over those matches; its results stay in the three members below, which the
+    // reference keeps as locals and prints.
     // Blending is the reference's own code, called only when this file is built
     // with SIFT_AMD_WITH_CONSUMERS.
     void Check(float matchTh = NN_SQ_DIST_RATIO_THR);

@@ -57,6 +57,13 @@ int main(int argc, char** argv) {
         Stitching match(fea1, fea2);
         sift_amd::ransac_seed() = 1234;  // reproducible sample stream for the checker
         match.Check(th);
+        // Check() ran RANSAC on the GPU; the CPU implementation must agree bit for bit
+        Feature** cpu_in = nullptr;
+        int cpu_n = 0;
+        const std::vector<float> cpu_H = ransac_xform(fea2.FeatStart, (int)fea2.feaNum, 4, 0.005f, 3.f, &cpu_in, cpu_n);
+        bool ransac_equal = cpu_H == match.HomogMat && cpu_n == match.RANSAC_num;
+        for (int i = 0; ransac_equal && i < cpu_n; i++) ransac_equal = cpu_in[i] == match.RANSAC_feat[i];
+        delete[] cpu_in;
         FILE* o = fopen(argv[2], "wb");
         if (!o) { perror("open output"); return 2; }
         const int32_t cnt[2] = {(int32_t)fea1.feaNum, (int32_t)fea2.feaNum};
@@ -85,8 +92,9 @@ int main(int argc, char** argv) {
             sy += fea3.FeatStart[i].img_pt.y;
         }
         printf("{\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
-               "\"sub_sum_y\": %.6f, \"ransac_num\": %d, \"homog\": [",
-               fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy, match.RANSAC_num);
+               "\"sub_sum_y\": %.6f, \"ransac_equal\": %s, \"ransac_num\": %d, \"homog\": [",
+               fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy, ransac_equal ? "true" : "false",
+               match.RANSAC_num);
         for (size_t i = 0; i < match.HomogMat.size(); i++) printf("%s%.9g", i ? ", " : "", match.HomogMat[i]);
         printf("], \"ransac_feat\": [");
         for (int i = 0; i < match.RANSAC_num; i++) printf("%s%d", i ? ", " : "", (int)(match.RANSAC_feat[i] - fea2.FeatStart));
