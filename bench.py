@@ -141,7 +141,7 @@ def main():
                 traffic = round((kk["read"] + kk["write"]) / kk["launches_per_frame"])
                 traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this workload, " \
                                "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, per launch; profiles/" + os.path.basename(tpath)
-        # VALU floor of the exact blur: 4.86 ns per wave-level (v_mul_f32, v_cvt_f64_f32, v_add_f64)
+        # VALU floor of the exact blur: 4.56 ns per wave-level (half a v_pk_mul_f32, v_cvt_f64_f32, v_add_f64)
         # triple per SIMD (tools/microbench_valu.hip), 1024 SIMDs
         # levels built as images: the library evaluates the last level only around top-layer
         # extrema (unless the sub-pixel stage is on), which the launch count shows
@@ -153,7 +153,7 @@ def main():
                 sig = 1.6 * (2.0 ** 0.5) ** i * (2.0 / size)
                 taps += px[o] * 2 * (int(round(6 * sig + 1)) | 1)
             size /= 2.0
-        valu_floor_ms = taps / 64.0 / 1024.0 * 4.86e-6
+        valu_floor_ms = taps / 64.0 / 1024.0 * 4.56e-6
         roofline = {
             "kernel": "%s (dominant kernel by total time; %d launches/frame)" % (kname or dom, n_dom),
             "bound": "hbm",
@@ -178,7 +178,7 @@ def main():
             "avg_launch_ms_by_class": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items() if v[1]},
             "stage_ms_per_frame": {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1]},
             "note": "blur_mode 0 keeps the reference's float-product / double-accumulate arithmetic bit for bit, "
-                    "which makes the blur fp64-VALU-bound (v_mul_f32 + v_cvt_f64_f32 + v_add_f64 per tap), not "
+                    "which makes the blur fp64-VALU-bound (half a v_pk_mul_f32 + v_cvt_f64_f32 + v_add_f64 per tap), not "
                     "HBM-bound; frac_of_valu_floor is the efficiency against that bound for the levels that are "
                     "built as images (the last level of each octave is evaluated only at the 3x3 neighbourhoods "
                     "of top-layer extrema, inside the detect class)",

@@ -100,17 +100,37 @@ constexpr int kMaxColLds = 64 * 1024;  // largest LDS tile a blur pass may reque
 // P = outputs per thread along the filter direction: 8 for large octaves (one LDS
 // read per 8 MACs), 4 and 2 for smaller ones, which otherwise cannot fill 1024 SIMDs.
 
-template <typename ACC>
-__device__ __forceinline__ void mac(ACC& acc, float a, float g);
-template <>
-__device__ __forceinline__ void mac<double>(double& acc, float a, float g) {
-    const float prod = a * g;  // rounded to float first, as `img[..] * gau_mat[k]` is
-    acc += (double)prod;
-}
-template <>
-__device__ __forceinline__ void mac<float>(float& acc, float a, float g) {
-    acc = fmaf(a, g, acc);
-}
+// The sliding window of a thread: P input values in a ring (slot = input index
+// mod P) and one tap step over all of them: acc[p] += win[(p + u) % P] * g.
+template <typename ACC, int P>
+struct Window {  // float accumulation (blur_mode 1): fused multiply-add
+    float v[P];
+    __device__ __forceinline__ void set(int slot, float x) { v[slot] = x; }
+    __device__ __forceinline__ void step(ACC (&acc)[P], int u, float g) const {
+#pragma unroll
+        for (int p = 0; p < P; p++) acc[p] = fmaf(v[(p + u) % P], g, acc[p]);
+    }
+};
+// Exact mode: the product is rounded to float first, as `img[..] * gau_mat[k]` is,
+// then added in double.  The slots are kept as register pairs so that one packed
+// multiply (v_pk_mul_f32, same rounding as two v_mul_f32) serves two outputs;
+// conversion and addition stay one instruction per output.
+typedef float float_pair __attribute__((ext_vector_type(2)));
+template <int P>
+struct Window<double, P> {
+    float_pair v[P / 2];
+    __device__ __forceinline__ void set(int slot, float x) {
+        if (slot & 1) v[slot >> 1].y = x; else v[slot >> 1].x = x;
+    }
+    __device__ __forceinline__ void step(double (&acc)[P], int u, float g) const {
+#pragma unroll
+        for (int i = 0; i < P / 2; i++) {
+            const float_pair prod = v[i] * g;
+            acc[(2 * i - u + P) % P] += (double)prod.x;      // slot s feeds output (s - u) mod P
+            acc[(2 * i + 1 - u + P) % P] += (double)prod.y;
+        }
+    }
+};
 
 // LDS index with one pad word per P so that lanes P floats apart hit distinct banks
 // (lane stride P+1 words, odd).
@@ -153,29 +173,27 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
     const int base = lane * P;
     if (x0 + base >= W) return;
     ACC acc[P];
-    float win[P];
+    Window<ACC, P> win;
 #pragma unroll
     for (int p = 0; p < P; p++) {
         acc[p] = 0;
-        win[p] = s[padx<P>(base + p)];
+        win.set(p, s[padx<P>(base + p)]);
     }
     int k = 0;
     for (; k + P <= K; k += P) {
 #pragma unroll
         for (int u = 0; u < P; u++) {
             const float g = taps[k + u];
-#pragma unroll
-            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = s[padx<P>(base + k + u + P)];
+            win.step(acc, u, g);
+            win.set(u, s[padx<P>(base + k + u + P)]);
         }
     }
 #pragma unroll
     for (int u = 0; u < P; u++) {
         if (k + u < K) {  // wave-uniform
             const float g = taps[k + u];
-#pragma unroll
-            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = s[padx<P>(base + k + u + P)];
+            win.step(acc, u, g);
+            win.set(u, s[padx<P>(base + k + u + P)]);
         }
     }
     float* o = out + (size_t)y * W + x0 + base;
@@ -208,29 +226,27 @@ __global__ __launch_bounds__(64) void blur_row_global_kernel(const float* __rest
     const float* row = in + (size_t)y * W;
     auto rd = [&](int xx) -> float { return row[max(0, min(xx, W - 1))]; };
     ACC acc[P];
-    float win[P];
+    Window<ACC, P> win;
 #pragma unroll
     for (int p = 0; p < P; p++) {
         acc[p] = 0;
-        win[p] = rd(xb + p - r);
+        win.set(p, rd(xb + p - r));
     }
     int k = 0;
     for (; k + P <= K; k += P) {
 #pragma unroll
         for (int u = 0; u < P; u++) {
             const float g = taps[k + u];
-#pragma unroll
-            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = rd(xb + k + u + P - r);
+            win.step(acc, u, g);
+            win.set(u, rd(xb + k + u + P - r));
         }
     }
 #pragma unroll
     for (int u = 0; u < P; u++) {
         if (k + u < K) {
             const float g = taps[k + u];
-#pragma unroll
-            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = rd(xb + k + u + P - r);
+            win.step(acc, u, g);
+            win.set(u, rd(xb + k + u + P - r));
         }
     }
 #pragma unroll
@@ -276,29 +292,27 @@ __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__
     for (int c = wave * P; c < TH; c += 4 * P) {
         if (y0 + c >= H) break;  // wave-uniform
         ACC acc[P];
-        float win[P];
+        Window<ACC, P> win;
 #pragma unroll
         for (int p = 0; p < P; p++) {
             acc[p] = 0;
-            win[p] = s[(c + p) * 64 + lane];
+            win.set(p, s[(c + p) * 64 + lane]);
         }
         int k = 0;
         for (; k + P <= K; k += P) {
 #pragma unroll
             for (int u = 0; u < P; u++) {
                 const float g = taps[k + u];
-#pragma unroll
-                for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-                win[u] = s[(c + k + u + P) * 64 + lane];
+                win.step(acc, u, g);
+                win.set(u, s[(c + k + u + P) * 64 + lane]);
             }
         }
 #pragma unroll
         for (int u = 0; u < P; u++) {
             if (k + u < K) {
                 const float g = taps[k + u];
-#pragma unroll
-                for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-                win[u] = s[(c + k + u + P) * 64 + lane];
+                win.step(acc, u, g);
+                win.set(u, s[(c + k + u + P) * 64 + lane]);
             }
         }
         if (x < W) {
@@ -330,29 +344,27 @@ __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __res
         return in[(size_t)yy * W + x];
     };
     ACC acc[P];
-    float win[P];
+    Window<ACC, P> win;
 #pragma unroll
     for (int p = 0; p < P; p++) {
         acc[p] = 0;
-        win[p] = rd(yb + p - r);
+        win.set(p, rd(yb + p - r));
     }
     int k = 0;
     for (; k + P <= K; k += P) {
 #pragma unroll
         for (int u = 0; u < P; u++) {
             const float g = taps[k + u];
-#pragma unroll
-            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = rd(yb + k + u + P - r);
+            win.step(acc, u, g);
+            win.set(u, rd(yb + k + u + P - r));
         }
     }
 #pragma unroll
     for (int u = 0; u < P; u++) {
         if (k + u < K) {
             const float g = taps[k + u];
-#pragma unroll
-            for (int p = 0; p < P; p++) mac<ACC>(acc[p], win[(p + u) % P], g);
-            win[u] = rd(yb + k + u + P - r);
+            win.step(acc, u, g);
+            win.set(u, rd(yb + k + u + P - r));
         }
     }
 #pragma unroll

@@ -87,3 +87,26 @@ def test_cpp_classes_rgb_input(tmp_path, oracle):
     assert len(f1) == len(fo) and np.array_equal(f1["y"], fo["y"])
     # identical images: every feature's nearest neighbour is itself at distance 0
     assert info["n1"] == info["n2"]
+
+
+def test_plumbing_config_rgb_pair_640x480(tmp_path, sift, oracle):
+    """The reference's own use (Sift_main.cpp:31-55) on a synthetic RGB pair, second image =
+    first moved 40 px: Sift -> Sift -> Stitching::Check(0.5) through the C++ classes; the match
+    list equals the oracle's exact search and RANSAC returns that translation."""
+    g1 = sift_amd.blob_image(640, 480, seed=7)
+    g2 = sift_amd.blob_image(640, 480, seed=7, shift_x=-40)
+    rgb = lambda g: np.stack([g, g * np.float32(0.95), g * np.float32(0.9)], axis=-1)  # noqa: E731
+    info, f1, f2, m = run_selftest(tmp_path, rgb(g1), rgb(g2), 0.5)
+    fo1, _ = oracle.extract(oracle.convert_gray(rgb(g1)))
+    fo2, _ = oracle.extract(oracle.convert_gray(rgb(g2)))
+    assert len(f1) == len(fo1) and len(f2) == len(fo2)
+    for k in ("x", "y", "kai", "sita"):
+        assert np.array_equal(f1[k], fo1[k]) and np.array_equal(f2[k], fo2[k])
+    bo, _, _ = oracle.match_u8(f2["descr"], f1["descr"], 0.5, 0)
+    assert np.array_equal(m, bo) and (bo >= 0).sum() > 100
+    assert info["ransac_equal"] is True and info["ransac_num"] > 0.8 * (bo >= 0).sum()
+    H = np.array(info["homog"])
+    for cx, cy in ((100.0, 100.0), (320.0, 240.0), (600.0, 400.0)):
+        den = H[6] * cx + H[7] * cy + H[8]
+        mx, my = (H[0] * cx + H[1] * cy + H[2]) / den - cx, (H[3] * cx + H[4] * cy + H[5]) / den - cy
+        assert abs(abs(mx) - 40.0) < 1.0 and abs(my) < 1.0

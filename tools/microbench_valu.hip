@@ -25,7 +25,17 @@ __global__ __launch_bounds__(256) void k(const float* in, float* out, float g0) 
             if (MODE == 5) { a[i] = __builtin_fmaf(a[i], g, 0.5f); }          // fma_f32
             if (MODE == 6) { float p = a[i] * g; float t = (float)acc[i] + p; acc[i] = t; } // f32 add chain (in double var)
         }
-        if (MODE == 0 || MODE == 2 || MODE == 3) g += 1e-9f;
+        if (MODE == 7 || MODE == 8) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f2 v = {a[2 * i], a[2 * i + 1]};
+                v = v * g;                                                    // one v_pk_mul_f32 for two statements
+                if (MODE == 7) { acc[2 * i] += (double)v.x; acc[2 * i + 1] += (double)v.y; }
+                if (MODE == 8) { a[2 * i] = v.x; a[2 * i + 1] = v.y; }
+            }
+        }
+        if (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 7 || MODE == 8) g += 1e-9f;
     }
     float s = 0;
     for (int i = 0; i < 8; i++) s += (float)acc[i] + a[i];
@@ -67,5 +77,7 @@ int main() {
     run<4>("fma_f64", 1);
     run<5>("fma_f32", 1);
     run<6>("mul+cvt32<-64+add32+cvt64", 4);
+    run<7>("pk_mul_f32/2+cvt_f64+add_f64", 3);
+    run<8>("pk_mul_f32/2", 1);
     return 0;
 }
