@@ -183,6 +183,27 @@ int sift_hip_ransac_homog_dev(sift_hip_ctx* ctx, const sift_hip_feat* d_q_feats,
                               float err_tol, unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in,
                               int32_t* iterations);
 
+/* ---- geometric warps of the stitcher: replace _WarpPerspective and warping, ----------
+ * Sift/stitch/stitch.cpp:106-141 and :178-221 (call sites: blen2img, Blend.cpp:922, :974).
+ * Images are interleaved 8-bit RGB, row-major, cols x rows.
+ * warp_perspective: dst pixel (column j, row i) samples src bilinearly (stitch.cpp:19-63)
+ * at the position the closed-form inverse of H9 (row-major 3x3, as ransac_xform returns it)
+ * gives; dst is in/out: pixels whose position falls outside src keep their value, samples
+ * whose 2x2 neighbourhood leaves src are black, as in the reference. */
+int sift_hip_warp_perspective(sift_hip_ctx* ctx, const uint8_t* src_rgb, int s_col, int s_row, const float* H9,
+                              uint8_t* dst_rgb, int d_col, int d_row);
+/* src and dst in device memory (H9 stays a host pointer); runs on the context's stream, no host sync. */
+int sift_hip_warp_perspective_dev(sift_hip_ctx* ctx, const uint8_t* d_src_rgb, int s_col, int s_row, const float* H9,
+                                  uint8_t* d_dst_rgb, int d_col, int d_row);
+/* warp_cylinder: the cylindrical projection with focal length `focal` (> 0) of one w x h image
+ * into out_rgb (w x h, every pixel written, black where the source position leaves the image);
+ * upedge / downedge (optional, 2 * w floats each) receive the (x, y) source positions of the
+ * first and the last output row. */
+int sift_hip_warp_cylinder(sift_hip_ctx* ctx, const uint8_t* src_rgb, int w, int h, float focal, uint8_t* out_rgb,
+                           float* upedge, float* downedge);
+int sift_hip_warp_cylinder_dev(sift_hip_ctx* ctx, const uint8_t* d_src_rgb, int w, int h, float focal,
+                               uint8_t* d_out_rgb, float* d_upedge, float* d_downedge);
+
 /* ---- measurement ------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; totals are kept per kernel class. */
@@ -200,7 +221,8 @@ enum {
     SIFT_HIP_K_BLUR_ROW_SMALL = 10, /* the blur passes of octaves below 3 Mpixel (fewer outputs per thread) */
     SIFT_HIP_K_BLUR_COL_SMALL = 11,
     SIFT_HIP_K_RANSAC = 12, /* pair gather, sample fits, consensus counts */
-    SIFT_HIP_K_COUNT = 13
+    SIFT_HIP_K_WARP = 13,   /* perspective and cylindrical warps */
+    SIFT_HIP_K_COUNT = 14
 };
 int sift_hip_profile(sift_hip_ctx* ctx, int enable);
 /* Synchronises, then fills ms[k] = summed kernel time and launches[k] = launch

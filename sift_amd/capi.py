@@ -29,7 +29,7 @@ FEAT_DTYPE = np.dtype(
 assert FEAT_DTYPE.itemsize == 156
 
 KERNEL_CLASSES = ("resample", "blur_row", "blur_col", "detect", "compact", "orient", "emit", "descr", "match", "gray",
-                  "blur_row_small", "blur_col_small", "ransac")
+                  "blur_row_small", "blur_col_small", "ransac", "warp")
 
 OK, ERR_ARG, ERR_NOSPC, ERR_HIP, ERR_NOMEM, ERR_SAME, ERR_NODEVICE, ERR_LIMIT = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -115,6 +115,10 @@ def load_library() -> C.CDLL:
                                             vp, vp, ip, ip]),
         "sift_hip_ransac_homog_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float,
                                                 C.c_uint, vp, vp, ip, ip]),
+        "sift_hip_warp_perspective": (C.c_int, [vp, vp, C.c_int, C.c_int, fp, vp, C.c_int, C.c_int]),
+        "sift_hip_warp_perspective_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, fp, vp, C.c_int, C.c_int]),
+        "sift_hip_warp_cylinder": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
+        "sift_hip_warp_cylinder_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
         "sift_hip_kernel_class_name": (C.c_char_p, [C.c_int]),
@@ -319,6 +323,28 @@ class SiftHip:
         if n_in.value < 0:
             return None, idx[:0], iters.value
         return H.reshape(3, 3), idx[:n_in.value].copy(), iters.value
+
+    # ---- geometric warps of the stitcher ----------------------------------------------
+    def warp_perspective(self, src_rgb: np.ndarray, H, dst_rgb: np.ndarray) -> np.ndarray:
+        """_WarpPerspective (stitch/stitch.cpp:106-141); dst_rgb (rows, cols, 3) uint8 is updated in place."""
+        src = np.ascontiguousarray(src_rgb, np.uint8)
+        assert src.ndim == 3 and src.shape[2] == 3 and dst_rgb.dtype == np.uint8 and dst_rgb.flags.c_contiguous
+        Hm = np.ascontiguousarray(H, np.float32).reshape(9)
+        self._check(self.lib.sift_hip_warp_perspective(self.h, _ptr(src), src.shape[1], src.shape[0],
+                                                       Hm.ctypes.data_as(C.POINTER(C.c_float)), _ptr(dst_rgb),
+                                                       dst_rgb.shape[1], dst_rgb.shape[0]))
+        return dst_rgb
+
+    def warp_cylinder(self, src_rgb: np.ndarray, focal: float):
+        """warping (stitch/stitch.cpp:178-221) for one image: (out, upedge (w, 2), downedge (w, 2))."""
+        src = np.ascontiguousarray(src_rgb, np.uint8)
+        assert src.ndim == 3 and src.shape[2] == 3
+        h, w = src.shape[:2]
+        out = np.empty_like(src)
+        up = np.zeros((w, 2), np.float32)
+        down = np.zeros((w, 2), np.float32)
+        self._check(self.lib.sift_hip_warp_cylinder(self.h, _ptr(src), w, h, focal, _ptr(out), _ptr(up), _ptr(down)))
+        return out, up, down
 
     # ---- measurement ----------------------------------------------------------------
     def profile(self, enable: bool):

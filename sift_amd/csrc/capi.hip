@@ -597,7 +597,8 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
                       &ctx->gcounters, &ctx->gcounters_alt, &ctx->gathered, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all,
                       &ctx->ransac.blk, &ctx->ransac.pairs, &ctx->ransac.src, &ctx->ransac.flags, &ctx->ransac.samples,
-                      &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best};
+                      &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best,
+                      &ctx->warp_src, &ctx->warp_dst, &ctx->warp_edges};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
@@ -911,6 +912,66 @@ int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t
     return check_async(ctx, "match");
 }
 
+// Largest image the warps index with 32-bit pixel counts.
+static bool warp_size_bad(int cols, int rows) {
+    return cols <= 0 || rows <= 0 || (size_t)cols * (size_t)rows > ((size_t)1 << 30);
+}
+
+int sift_hip_warp_perspective_dev(sift_hip_ctx* ctx, const uint8_t* d_src_rgb, int s_col, int s_row, const float* H9,
+                                  uint8_t* d_dst_rgb, int d_col, int d_row) {
+    if (bad_ctx(ctx) || !d_src_rgb || !d_dst_rgb || !H9 || d_src_rgb == d_dst_rgb) return SIFT_HIP_ERR_ARG;
+    if (warp_size_bad(s_col, s_row) || warp_size_bad(d_col, d_row)) return SIFT_HIP_ERR_ARG;
+    launch_warp_perspective(ctx, ctx->stream, d_src_rgb, s_col, s_row, H9, d_dst_rgb, d_col, d_row);
+    return check_async(ctx, "warp_perspective launch");
+}
+
+int sift_hip_warp_perspective(sift_hip_ctx* ctx, const uint8_t* src_rgb, int s_col, int s_row, const float* H9,
+                              uint8_t* dst_rgb, int d_col, int d_row) {
+    if (bad_ctx(ctx) || !src_rgb || !dst_rgb || !H9 || src_rgb == dst_rgb) return SIFT_HIP_ERR_ARG;
+    if (warp_size_bad(s_col, s_row) || warp_size_bad(d_col, d_row)) return SIFT_HIP_ERR_ARG;
+    const size_t sb = (size_t)s_col * s_row * 3, db = (size_t)d_col * d_row * 3;
+    int rc;
+    if ((rc = ensure(ctx, ctx->warp_src, sb))) return rc;
+    if ((rc = ensure(ctx, ctx->warp_dst, db))) return rc;
+    hipMemcpyAsync(ctx->warp_src.p, src_rgb, sb, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(ctx->warp_dst.p, dst_rgb, db, hipMemcpyHostToDevice, ctx->stream);  // in/out
+    launch_warp_perspective(ctx, ctx->stream, (const uint8_t*)ctx->warp_src.p, s_col, s_row, H9,
+                            (uint8_t*)ctx->warp_dst.p, d_col, d_row);
+    hipMemcpyAsync(dst_rgb, ctx->warp_dst.p, db, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "warp_perspective")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "warp_perspective");
+}
+
+int sift_hip_warp_cylinder_dev(sift_hip_ctx* ctx, const uint8_t* d_src_rgb, int w, int h, float focal,
+                               uint8_t* d_out_rgb, float* d_upedge, float* d_downedge) {
+    if (bad_ctx(ctx) || !d_src_rgb || !d_out_rgb || d_src_rgb == d_out_rgb || warp_size_bad(w, h) || !(focal > 0.f))
+        return SIFT_HIP_ERR_ARG;
+    launch_warp_cylinder(ctx, ctx->stream, d_src_rgb, w, h, focal, d_out_rgb, d_upedge, d_downedge);
+    return check_async(ctx, "warp_cylinder launch");
+}
+
+int sift_hip_warp_cylinder(sift_hip_ctx* ctx, const uint8_t* src_rgb, int w, int h, float focal, uint8_t* out_rgb,
+                           float* upedge, float* downedge) {
+    if (bad_ctx(ctx) || !src_rgb || !out_rgb || src_rgb == out_rgb || warp_size_bad(w, h) || !(focal > 0.f))
+        return SIFT_HIP_ERR_ARG;
+    const size_t nb = (size_t)w * h * 3, eb = (size_t)w * 2 * sizeof(float);
+    int rc;
+    if ((rc = ensure(ctx, ctx->warp_src, nb))) return rc;
+    if ((rc = ensure(ctx, ctx->warp_dst, nb))) return rc;
+    if ((rc = ensure(ctx, ctx->warp_edges, 2 * eb))) return rc;
+    float* d_up = (float*)ctx->warp_edges.p;
+    float* d_down = d_up + (size_t)w * 2;
+    hipMemcpyAsync(ctx->warp_src.p, src_rgb, nb, hipMemcpyHostToDevice, ctx->stream);
+    hipMemsetAsync(ctx->warp_edges.p, 0, 2 * eb, ctx->stream);  // a one-row image has no separate last row
+    launch_warp_cylinder(ctx, ctx->stream, (const uint8_t*)ctx->warp_src.p, w, h, focal, (uint8_t*)ctx->warp_dst.p, d_up,
+                         d_down);
+    hipMemcpyAsync(out_rgb, ctx->warp_dst.p, nb, hipMemcpyDeviceToHost, ctx->stream);
+    if (upedge) hipMemcpyAsync(upedge, d_up, eb, hipMemcpyDeviceToHost, ctx->stream);
+    if (downedge) hipMemcpyAsync(downedge, d_down, eb, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "warp_cylinder")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "warp_cylinder");
+}
+
 static int ransac_args_bad(sift_hip_ctx* ctx, const void* q, int nq, const void* r, int nr, const void* best, int m,
                            float p_badxform, float err_tol, const int32_t* n_in) {
     if (bad_ctx(ctx) || nq < 0 || nr < 0 || !n_in || (nq > 0 && (!q || !best)) || (nr > 0 && !r)) return 1;
@@ -985,7 +1046,7 @@ int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset
 const char* sift_hip_kernel_class_name(int k) {
     static const char* names[SIFT_HIP_K_COUNT] = {"resample", "blur_row", "blur_col", "detect", "compact", "orient",
                                                   "emit",     "descr",    "match",    "gray",   "blur_row_small",
-                                                  "blur_col_small", "ransac"};
+                                                  "blur_col_small", "ransac", "warp"};
     return (k >= 0 && k < SIFT_HIP_K_COUNT) ? names[k] : "?";
 }
 

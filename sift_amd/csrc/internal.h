@@ -94,6 +94,7 @@ struct sift_hip_ctx {
     sifthip::DevBuf gcounters_alt;
     sifthip::DevBuf gathered;  // all ranks' reference descriptors (sharded match)
     sifthip::RansacWs ransac;
+    sifthip::DevBuf warp_src, warp_dst, warp_edges;
     hipEvent_t ev_frame[2] = {nullptr, nullptr};
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
@@ -159,6 +160,11 @@ void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const f
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
               int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
 
+// warp.hip
+void launch_warp_perspective(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_src, int s_col, int s_row,
+                             const float* H9, uint8_t* d_dst, int d_col, int d_row);
+void launch_warp_cylinder(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_src, int w, int h, float focal,
+                          uint8_t* d_out, float* d_upedge, float* d_downedge);
 // ransac.hip; features and best in device memory, outputs in host memory
 int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_hip_feat* d_r, int nr,
                const int32_t* d_best, int m, float p_badxform, float err_tol, unsigned seed, float* H9,

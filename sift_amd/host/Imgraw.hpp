@@ -30,6 +30,13 @@ public:
 
     operator std::vector<types>&() { return raw_img; }
     operator const std::vector<types>&() const { return raw_img; }
+    // 8-bit copy (Imgraw.hpp:59-82): what the stitcher's Raw images are filled from
+    operator std::vector<unsigned char>() const {
+        std::vector<unsigned char> img(raw_img.size());
+        for (size_t i = 0; i < raw_img.size(); ++i)
+            img[i] = nomal ? (unsigned char)(raw_img[i] * ImgRawPixMax) : (unsigned char)raw_img[i];
+        return img;
+    }
     types& operator[](size_t idx) { return raw_img[idx]; }
     const types& operator[](size_t idx) const { return raw_img[idx]; }
     types& at2d(size_t y, size_t x) { return raw_img[y * width + x]; }

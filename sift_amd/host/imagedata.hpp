@@ -1,14 +1,36 @@
 // Keypoint record shared with the RANSAC / blend consumers.
 // Mirrors the public layout of the reference's Sift/imagedata.hpp:9-86 (fpoint,
-// Feature) so that code written against it compiles unchanged: same member
+// Raw, Feature) so that code written against it compiles unchanged: same member
 // names, types and order, same rX()/rY() helpers.
 #pragma once
+#include <cstddef>
+#include <vector>
 
 struct fpoint {
     fpoint() : x(0.f), y(0.f) {}
     fpoint(float px, float py) : x(px), y(py) {}
     float x;
     float y;
+};
+
+// Interleaved 8-bit RGB image of the stitcher (imagedata.hpp:17-33).
+class Raw {
+public:
+    Raw() = default;
+    Raw(size_t w, size_t h) : RGB(w * h * 3), col(w), row(h) {}
+    void resize(size_t w, size_t h) {
+        RGB.resize(w * h * 3);
+        col = w, row = h;
+    }
+    int getCol() const { return (int)col; }
+    int getRow() const { return (int)row; }
+
+public:
+    std::vector<unsigned char> RGB;
+
+protected:
+    size_t col = 0;
+    size_t row = 0;
 };
 
 struct Feature {

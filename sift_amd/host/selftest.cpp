@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "Sift.hpp"
+#include "stitch.hpp"
 
 #pragma pack(push, 1)
 struct Rec {
@@ -78,6 +79,38 @@ int main(int argc, char** argv) {
             fwrite(&idx, 4, 1, o);
         }
         fclose(o);
+        // the stitcher's warps as blen2img calls them (Blend.cpp:907-922, :974), for RGB input:
+        // <out.bin>.warp = int32 cols, rows + bytes of the perspective canvas, then for each of the
+        // two cylinder outputs int32 cols, rows + bytes, then int32 n + n (x, y) floats of upedge, downedge
+        if (ch == 3 && match.HomogMat.size() == 9) {
+            auto to_raw = [](const ImgRaw& src) {
+                Raw dst(src.width, src.height);
+                dst.RGB = src;
+                return dst;
+            };
+            std::vector<Raw> in = {to_raw(img1), to_raw(img2)};
+            Raw warpImg((size_t)(in[1].getCol() * 1.6), (size_t)(in[1].getRow() * 1.1));
+            _WarpPerspective(in[1], warpImg, match.HomogMat);
+            std::vector<Raw> cyl;
+            std::vector<fpoint> up, down;
+            warping(in, 700.f, cyl, up, down);
+            FILE* wf = fopen((std::string(argv[2]) + ".warp").c_str(), "wb");
+            if (!wf) { perror("open warp output"); return 2; }
+            auto put = [&](const Raw& r) {
+                const int32_t d[2] = {r.getCol(), r.getRow()};
+                fwrite(d, 4, 2, wf);
+                fwrite(r.RGB.data(), 1, r.RGB.size(), wf);
+            };
+            put(warpImg);
+            put(cyl[0]);
+            put(cyl[1]);
+            for (const std::vector<fpoint>* e : {&up, &down}) {
+                const int32_t n = (int32_t)e->size();
+                fwrite(&n, 4, 1, wf);
+                for (const fpoint& p : *e) { fwrite(&p.x, 4, 1, wf); fwrite(&p.y, 4, 1, wf); }
+            }
+            fclose(wf);
+        }
         // the image-op mirrors: blur into the same vector must throw file_same
         bool threw = false;
         try { Gaus::GauBlur(img1.raw_img, img1.raw_img, w, h, 1.6f); } catch (const file_same&) { threw = true; }

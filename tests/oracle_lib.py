@@ -49,7 +49,27 @@ class Oracle:
                                      C.c_double, vp]
         o.orc_force_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp]
         o.orc_match_u8.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]
+        o.orc_warp_perspective.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]
+        o.orc_warp_cylinder.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]
         self.o = o
+
+    def warp_perspective(self, src_rgb, H, dst_rgb):
+        """_WarpPerspective (stitch.cpp:106-141); returns the updated copy of dst_rgb."""
+        src = np.ascontiguousarray(src_rgb, np.uint8)
+        dst = np.array(dst_rgb, np.uint8, copy=True, order="C")
+        Hm = np.ascontiguousarray(H, np.float32).reshape(9)
+        self.o.orc_warp_perspective(_p(src), src.shape[1], src.shape[0], _p(Hm), _p(dst), dst.shape[1], dst.shape[0])
+        return dst
+
+    def warp_cylinder(self, src_rgb, focal):
+        """warping (stitch.cpp:178-221) for one image: (out, upedge, downedge)."""
+        src = np.ascontiguousarray(src_rgb, np.uint8)
+        h, w = src.shape[:2]
+        out = np.zeros_like(src)
+        up = np.zeros((w, 2), np.float32)
+        down = np.zeros((w, 2), np.float32)
+        self.o.orc_warp_cylinder(_p(src), w, h, focal, _p(out), _p(up), _p(down))
+        return out, up, down
 
     def gau_matrix(self, p, mat_len=0):
         buf = np.zeros(8192, np.float32)

@@ -110,3 +110,34 @@ def test_plumbing_config_rgb_pair_640x480(tmp_path, sift, oracle):
         den = H[6] * cx + H[7] * cy + H[8]
         mx, my = (H[0] * cx + H[1] * cy + H[2]) / den - cx, (H[3] * cx + H[4] * cy + H[5]) / den - cy
         assert abs(abs(mx) - 40.0) < 1.0 and abs(my) < 1.0
+    # the stitcher's warps through the C++ mirrors (_WarpPerspective, warping) = oracle, byte for byte
+    raw = open(str(tmp_path / "out.bin") + ".warp", "rb").read()
+    pos = 0
+
+    def take_img():
+        nonlocal pos
+        c, r = np.frombuffer(raw[pos:pos + 8], np.int32)
+        img = np.frombuffer(raw[pos + 8:pos + 8 + c * r * 3], np.uint8).reshape(r, c, 3)
+        pos += 8 + c * r * 3
+        return img
+
+    def take_pts():
+        nonlocal pos
+        n = int(np.frombuffer(raw[pos:pos + 4], np.int32)[0])
+        pts = np.frombuffer(raw[pos + 4:pos + 4 + 8 * n], np.float32).reshape(n, 2)
+        pos += 4 + 8 * n
+        return pts
+
+    to_u8 = lambda a: (a.astype(np.float32).astype(np.float64) * 255.0).astype(np.uint8)  # noqa: E731  Imgraw.hpp:59-70
+    u1, u2 = to_u8(rgb(g1)), to_u8(rgb(g2))
+    canvas = take_img()
+    assert canvas.shape == (int(480 * 1.1), int(640 * 1.6), 3)
+    want = oracle.warp_perspective(u2, np.array(info["homog"], np.float32), np.zeros_like(canvas))
+    assert np.array_equal(canvas, want) and canvas.any()
+    up_all, down_all = [], []
+    for u in (u1, u2):
+        w_img, w_up, w_down = oracle.warp_cylinder(u, 700.0)
+        assert np.array_equal(take_img(), w_img)
+        up_all.append(w_up)
+        down_all.append(w_down)
+    assert np.array_equal(take_pts(), np.concatenate(up_all)) and np.array_equal(take_pts(), np.concatenate(down_all))

@@ -170,3 +170,18 @@ def test_subpixel_only_drops_or_moves_keypoints(orc):
     f2, _, _ = orc.extract_ex(img, describe=False, subpixel=1, contr_thr=0.05)
     assert len(f2) < len(f1) <= len(f0)
     assert (np.abs(s1) < 0.5).all()
+
+
+def test_stitch_warp_restatement_sanity(oracle):
+    """oracle/stitch_oracle.cpp (parity unpinned): identity homography copies the interior and
+    blacks the last row/column (stitch.cpp:39); the cylinder leaves the centre column in place."""
+    rng = np.random.default_rng(0)
+    src = rng.integers(1, 255, (40, 60, 3)).astype(np.uint8)
+    got = oracle.warp_perspective(src, [1, 0, 0, 0, 1, 0, 0, 0, 1], np.full((40, 60, 3), 9, np.uint8))
+    assert np.array_equal(got[:39, :59], src[:39, :59]) and (got[39] == 0).all() and (got[:, 59] == 0).all()
+    shifted = oracle.warp_perspective(src, [1, 0, 5, 0, 1, 0, 0, 0, 1], np.zeros((40, 80, 3), np.uint8))
+    assert np.array_equal(shifted[:39, 5:64], src[:39, :59]) and (shifted[:, :5] == 0).all()
+    out, up, down = oracle.warp_cylinder(src, 100.0)
+    assert np.array_equal(out[:39, 30], src[:39, 30])  # k = 1 on the axis
+    assert up.shape == (60, 2) and up[30, 0] == 30.0 and down[30, 1] > up[30, 1]
+    assert (out[:, 0] == 0).all()  # the outermost columns sample outside the image
