@@ -183,6 +183,14 @@ int sift_hip_ransac_homog_dev(sift_hip_ctx* ctx, const sift_hip_feat* d_q_feats,
                               float err_tol, unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in,
                               int32_t* iterations);
 
+/* The same over pairs the caller has formed: xyuv = n x (x, y, u, v) floats in host memory,
+ * (x, y) a matched feature's position and (u, v) its match's, in the order ransac_xform
+ * would meet them (ascending feature index).  inlier_idx (capacity n) = pair indices. */
+int sift_hip_ransac_homog_pairs(sift_hip_ctx* ctx, const float* xyuv, int n, int m, float p_badxform, float err_tol,
+                                unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in, int32_t* iterations);
+/* All three forms draw from libc's process-wide rand(), as the reference does: calls that
+ * overlap in time in several threads interleave their sample streams. */
+
 /* ---- geometric warps of the stitcher: replace _WarpPerspective and warping, ----------
  * Sift/stitch/stitch.cpp:106-141 and :178-221 (call sites: blen2img, Blend.cpp:922, :974).
  * Images are interleaved 8-bit RGB, row-major, cols x rows.

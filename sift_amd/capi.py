@@ -115,6 +115,8 @@ def load_library() -> C.CDLL:
                                             vp, vp, ip, ip]),
         "sift_hip_ransac_homog_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float,
                                                 C.c_uint, vp, vp, ip, ip]),
+        "sift_hip_ransac_homog_pairs": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint, vp, vp, ip,
+                                                  ip]),
         "sift_hip_warp_perspective": (C.c_int, [vp, vp, C.c_int, C.c_int, fp, vp, C.c_int, C.c_int]),
         "sift_hip_warp_perspective_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, fp, vp, C.c_int, C.c_int]),
         "sift_hip_warp_cylinder": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
@@ -320,6 +322,21 @@ class SiftHip:
         self._check(self.lib.sift_hip_ransac_homog(self.h, _ptr(q_feats), nq, _ptr(r_feats), nr, _ptr(best), m,
                                                    p_badxform, err_tol, seed, _ptr(H), _ptr(idx), C.byref(n_in),
                                                    C.byref(iters)))
+        if n_in.value < 0:
+            return None, idx[:0], iters.value
+        return H.reshape(3, 3), idx[:n_in.value].copy(), iters.value
+
+    def ransac_homog_pairs(self, xyuv: np.ndarray, m: int = 4, p_badxform: float = 0.005, err_tol: float = 3.0,
+                           seed: int = 0):
+        """The same over n x (x, y, u, v) pairs; returns (H or None, pair indices of the consensus, samples used)."""
+        xyuv = np.ascontiguousarray(xyuv, np.float32).reshape(-1, 4)
+        n = len(xyuv)
+        H = np.zeros(9, np.float32)
+        idx = np.full(max(n, 1), -1, np.int32)
+        n_in = C.c_int(0)
+        iters = C.c_int(0)
+        self._check(self.lib.sift_hip_ransac_homog_pairs(self.h, _ptr(xyuv), n, m, p_badxform, err_tol, seed, _ptr(H),
+                                                         _ptr(idx), C.byref(n_in), C.byref(iters)))
         if n_in.value < 0:
             return None, idx[:0], iters.value
         return H.reshape(3, 3), idx[:n_in.value].copy(), iters.value

@@ -1009,6 +1009,15 @@ int sift_hip_ransac_homog(sift_hip_ctx* ctx, const sift_hip_feat* q_feats, int n
                                      iterations);
 }
 
+int sift_hip_ransac_homog_pairs(sift_hip_ctx* ctx, const float* xyuv, int n, int m, float p_badxform, float err_tol,
+                                unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in, int32_t* iterations) {
+    if (bad_ctx(ctx) || n < 0 || !n_in || (n > 0 && !xyuv)) return SIFT_HIP_ERR_ARG;
+    if (m < 4 || m > 8 || !(p_badxform > 0.f) || !(p_badxform < 1.f) || !(err_tol >= 0.f)) return SIFT_HIP_ERR_ARG;
+    const int rc = run_ransac_pairs(ctx, xyuv, n, m, p_badxform, err_tol, seed, H9, inlier_idx, n_in, iterations);
+    if (rc) return rc;
+    return check_async(ctx, "ransac");
+}
+
 int sift_hip_last_offsets(sift_hip_ctx* ctx, float* xyz, int cap) {
     if (!ctx || cap < 0 || (cap > 0 && !xyz)) return SIFT_HIP_ERR_ARG;
     const int n = (int)std::min<size_t>(ctx->h_sub.size() / 3, (size_t)cap);

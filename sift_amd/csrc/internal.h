@@ -169,5 +169,7 @@ void launch_warp_cylinder(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_sr
 int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_hip_feat* d_r, int nr,
                const int32_t* d_best, int m, float p_badxform, float err_tol, unsigned seed, float* H9,
                int32_t* inlier_idx, int32_t* n_in, int32_t* iterations);
+int run_ransac_pairs(sift_hip_ctx* ctx, const float* xyuv, int n, int m, float p_badxform, float err_tol,
+                     unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in, int32_t* iterations);
 
 }  // namespace sifthip

@@ -127,43 +127,18 @@ __global__ __launch_bounds__(PB) void flag_kernel(const float4* __restrict__ pai
 
 }  // namespace
 
-int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_hip_feat* d_r, int nr,
-               const int32_t* d_best, int m, float p_badxform, float err_tol, unsigned seed, float* H9,
-               int32_t* inlier_idx, int32_t* n_in, int32_t* iterations) {
+// The loop over device-resident pairs d_pairs[0..nm) (host copy: xyuv); srand() was
+// called by the entry point.  src maps pair -> reported index (null: identity).
+static int ransac_core(sift_hip_ctx* ctx, const float4* d_pairs, int nm, const float* xyuv, const int32_t* src, int m,
+                       float p_badxform, float err_tol, float* H9, int32_t* inlier_idx, int32_t* n_in,
+                       int32_t* iterations) {
     hipStream_t st = ctx->stream;
-    *n_in = -1;
-    if (iterations) *iterations = 0;
-    srand(seed ? seed : (unsigned)time(nullptr));  // xform.cpp:42
-    if (nq == 0 || nr == 0) return SIFT_HIP_OK;
-
-    // ---- matched pairs, in query order ---------------------------------------------
-    const int nblk = (nq + PB - 1) / PB;
-    int rc;
     RansacWs& ws = ctx->ransac;
-    if ((rc = ensure(ctx, ws.blk, (size_t)(nblk + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ws.pairs, (size_t)nq * sizeof(float4)))) return rc;
-    if ((rc = ensure(ctx, ws.src, (size_t)nq * 4))) return rc;
-    if ((rc = ensure(ctx, ws.flags, (size_t)nq))) return rc;
+    int rc;
+    if ((rc = ensure(ctx, ws.flags, (size_t)nm))) return rc;
     if ((rc = ensure(ctx, ws.samples, (size_t)MAX_BATCH * MAX_M * 4))) return rc;
     if ((rc = ensure(ctx, ws.models, (size_t)MAX_BATCH * 9 * 4))) return rc;
     if ((rc = ensure(ctx, ws.counts, (size_t)MAX_BATCH * 2 * 4))) return rc;
-    int32_t* d_blk = (int32_t*)ws.blk.p;
-    int32_t* d_total = d_blk + nblk;
-    float4* d_pairs = (float4*)ws.pairs.p;
-    int32_t* d_src = (int32_t*)ws.src.p;
-    {
-        ProfScope ps(ctx, SIFT_HIP_K_RANSAC, st);
-        pair_count_kernel<<<nblk, PB, 0, st>>>(d_best, nq, nr, d_blk);
-        pair_write_kernel<<<nblk, PB, 0, st>>>(d_q, d_r, d_best, nq, nr, d_blk, d_pairs, d_src, d_total);
-    }
-    int32_t nm = 0;
-    hipMemcpyAsync(&nm, d_total, 4, hipMemcpyDeviceToHost, st);
-    if (!hip_ok(ctx, hipStreamSynchronize(st), "ransac pairs")) return SIFT_HIP_ERR_HIP;
-    if (nm < m) return SIFT_HIP_OK;  // "not enough matches to compute xform" (xform.cpp:53-56)
-    std::vector<float> xyuv((size_t)nm * 4);
-    std::vector<int32_t> src((size_t)nm);
-    hipMemcpyAsync(xyuv.data(), d_pairs, (size_t)nm * 16, hipMemcpyDeviceToHost, st);
-    hipMemcpyAsync(src.data(), d_src, (size_t)nm * 4, hipMemcpyDeviceToHost, st);
 
     // ---- the sampling loop, in batches -----------------------------------------------
     const int in_min = sift_homog::ransac_min_inliers(nm, m, kProbBadSupp, p_badxform);
@@ -246,16 +221,69 @@ int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_h
     std::vector<int> best, fin;
     if (!consensus_of(best_model, best)) return SIFT_HIP_ERR_HIP;
     Model M{};
-    if (!sift_homog::fit_pairs(xyuv.data(), best.data(), (int)best.size(), M.h)) return SIFT_HIP_OK;
+    if (!sift_homog::fit_pairs(xyuv, best.data(), (int)best.size(), M.h)) return SIFT_HIP_OK;
     if (!consensus_of(M, fin)) return SIFT_HIP_ERR_HIP;
-    const std::vector<int> order = sift_homog::last_fit_order(xyuv.data(), fin);
-    const bool ok = sift_homog::fit_pairs(xyuv.data(), order.data(), (int)order.size(), M.h);
+    const std::vector<int> order = sift_homog::last_fit_order(xyuv, fin);
+    const bool ok = sift_homog::fit_pairs(xyuv, order.data(), (int)order.size(), M.h);
     if (!ok) return SIFT_HIP_OK;
     if (H9) std::memcpy(H9, M.h, sizeof M.h);
     if (inlier_idx)
-        for (size_t i = 0; i < fin.size(); i++) inlier_idx[i] = src[(size_t)fin[i]];
+        for (size_t i = 0; i < fin.size(); i++) inlier_idx[i] = src ? src[(size_t)fin[i]] : (int32_t)fin[i];
     *n_in = (int32_t)fin.size();
     return SIFT_HIP_OK;
+}
+
+
+int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_hip_feat* d_r, int nr,
+               const int32_t* d_best, int m, float p_badxform, float err_tol, unsigned seed, float* H9,
+               int32_t* inlier_idx, int32_t* n_in, int32_t* iterations) {
+    hipStream_t st = ctx->stream;
+    *n_in = -1;
+    if (iterations) *iterations = 0;
+    srand(seed ? seed : (unsigned)time(nullptr));  // xform.cpp:42
+    if (nq == 0 || nr == 0) return SIFT_HIP_OK;
+
+    // ---- matched pairs, in query order ---------------------------------------------
+    const int nblk = (nq + PB - 1) / PB;
+    int rc;
+    RansacWs& ws = ctx->ransac;
+    if ((rc = ensure(ctx, ws.blk, (size_t)(nblk + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ws.pairs, (size_t)nq * sizeof(float4)))) return rc;
+    if ((rc = ensure(ctx, ws.src, (size_t)nq * 4))) return rc;
+    int32_t* d_blk = (int32_t*)ws.blk.p;
+    int32_t* d_total = d_blk + nblk;
+    float4* d_pairs = (float4*)ws.pairs.p;
+    int32_t* d_src = (int32_t*)ws.src.p;
+    {
+        ProfScope ps(ctx, SIFT_HIP_K_RANSAC, st);
+        pair_count_kernel<<<nblk, PB, 0, st>>>(d_best, nq, nr, d_blk);
+        pair_write_kernel<<<nblk, PB, 0, st>>>(d_q, d_r, d_best, nq, nr, d_blk, d_pairs, d_src, d_total);
+    }
+    int32_t nm = 0;
+    hipMemcpyAsync(&nm, d_total, 4, hipMemcpyDeviceToHost, st);
+    if (!hip_ok(ctx, hipStreamSynchronize(st), "ransac pairs")) return SIFT_HIP_ERR_HIP;
+    if (nm < m) return SIFT_HIP_OK;  // "not enough matches to compute xform" (xform.cpp:53-56)
+    std::vector<float> xyuv((size_t)nm * 4);
+    std::vector<int32_t> src((size_t)nm);
+    hipMemcpyAsync(xyuv.data(), d_pairs, (size_t)nm * 16, hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(src.data(), d_src, (size_t)nm * 4, hipMemcpyDeviceToHost, st);
+    if (!hip_ok(ctx, hipStreamSynchronize(st), "ransac pairs")) return SIFT_HIP_ERR_HIP;
+    return ransac_core(ctx, d_pairs, nm, xyuv.data(), src.data(), m, p_badxform, err_tol, H9, inlier_idx, n_in,
+                       iterations);
+}
+
+// The same over pairs the caller has already formed: xyuv = n x (x, y, u, v) in host memory.
+int run_ransac_pairs(sift_hip_ctx* ctx, const float* xyuv, int n, int m, float p_badxform, float err_tol,
+                     unsigned seed, float* H9, int32_t* inlier_idx, int32_t* n_in, int32_t* iterations) {
+    *n_in = -1;
+    if (iterations) *iterations = 0;
+    srand(seed ? seed : (unsigned)time(nullptr));  // xform.cpp:42
+    if (n < m) return SIFT_HIP_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->ransac.pairs, (size_t)n * sizeof(float4)))) return rc;
+    hipMemcpyAsync(ctx->ransac.pairs.p, xyuv, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    return ransac_core(ctx, (const float4*)ctx->ransac.pairs.p, n, xyuv, nullptr, m, p_badxform, err_tol, H9,
+                       inlier_idx, n_in, iterations);
 }
 
 }  // namespace sifthip

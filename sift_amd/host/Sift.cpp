@@ -265,32 +265,27 @@ void Stitching::Check(float matchTh) {
     if (!sift_amd::options().ransac_on_gpu) {
         HomogMat = ransac_xform(feat2, (int)feat2_Count, 4, 0.005f, 3.f, &RANSAC_feat, RANSAC_num);
     } else {
-        // the same loop with the sample fits and consensus counts on the GPU; equal results
-        auto pack = [](const Feature* f, size_t n, std::vector<sift_hip_feat>& out) {
-            out.assign(n, sift_hip_feat{});
-            for (size_t i = 0; i < n; i++) {
-                out[i].size = f[i].size;
-                out[i].x = f[i].x;
-                out[i].y = f[i].y;
-            }
-        };
-        std::vector<sift_hip_feat> q, r;
-        pack(feat2, feat2_Count, q);
-        pack(feat1, feat1_Count, r);
-        std::vector<int32_t> best(feat2_Count), idx(feat2_Count);
+        // the same loop with the sample fits and consensus counts on the GPU; equal results.
+        // Pairs as ransac_xform forms them: matched features in index order, positions through rX()/rY().
+        std::vector<float> xyuv;
+        std::vector<Feature*> owner;
         for (size_t i = 0; i < feat2_Count; i++)
-            best[i] = feat2[i].fwd_match ? (int32_t)(feat2[i].fwd_match - feat1) : -1;
+            if (const Feature* mt = feat2[i].fwd_match) {
+                xyuv.insert(xyuv.end(), {feat2[i].rX(), feat2[i].rY(), mt->rX(), mt->rY()});
+                owner.push_back(feat2 + i);
+            }
+        std::vector<int32_t> idx(owner.size() + 1);
         float H9[9];
         int32_t n_in = -1;
         sift_hip_ctx* ctx = default_context();
-        check(ctx, sift_hip_ransac_homog(ctx, q.data(), (int)feat2_Count, r.data(), (int)feat1_Count, best.data(), 4,
-                                         0.005f, 3.f, sift_amd::ransac_seed(), H9, idx.data(), &n_in, nullptr),
-              "sift_hip_ransac_homog");
+        check(ctx, sift_hip_ransac_homog_pairs(ctx, xyuv.data(), (int)owner.size(), 4, 0.005f, 3.f,
+                                               sift_amd::ransac_seed(), H9, idx.data(), &n_in, nullptr),
+              "sift_hip_ransac_homog_pairs");
         HomogMat.clear();
         if (n_in >= 0) {
             HomogMat.assign(H9, H9 + 9);
-            RANSAC_feat = new Feature*[feat2_Count > 0 ? feat2_Count : 1];
-            for (int32_t i = 0; i < n_in; i++) RANSAC_feat[i] = feat2 + idx[(size_t)i];
+            RANSAC_feat = new Feature*[owner.size() + 1];
+            for (int32_t i = 0; i < n_in; i++) RANSAC_feat[i] = owner[(size_t)idx[(size_t)i]];
             RANSAC_num = n_in;
         }
     }

@@ -40,6 +40,13 @@ def test_equals_host_and_restatement(sift, host, name, seed, n2, out):  # noqa: 
         np.testing.assert_allclose(H.reshape(-1), Ho, rtol=2e-4, atol=1e-6)
     good = np.nonzero((d["match"] >= 0) & ~d["bad"])[0]
     assert np.isin(good, idx).mean() > 0.97
+    # the form that takes ready-made pairs: same model, indices in pair numbering
+    sel = np.nonzero(d["match"] >= 0)[0]
+    mi = d["match"][sel]
+    xyuv = np.stack([d["x2"][sel] / d["size2"][sel], d["y2"][sel] / d["size2"][sel], d["x1"][mi] / d["size1"][mi],
+                     d["y1"][mi] / d["size1"][mi]], axis=1).astype(np.float32)
+    Hp, idxp, itp = sift.ransac_homog_pairs(xyuv, seed=seed)
+    assert np.array_equal(Hp, H) and np.array_equal(sel[idxp], idx) and itp == iters
     # a second run on the same seed repeats itself
     H2, idx2, it2 = run_gpu(sift, d, seed)
     assert np.array_equal(H, H2) and np.array_equal(idx, idx2) and it2 == iters

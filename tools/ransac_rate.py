@@ -32,12 +32,20 @@ def main():
         for _ in range(reps):
             H, idx, iters = ctx.ransac_homog(q, r, d["match"], seed=5)
         t_gpu = (time.perf_counter() - t0) / reps
+        sel = np.nonzero(d["match"] >= 0)[0]
+        mi = d["match"][sel]
+        xyuv = np.stack([d["x2"][sel] / d["size2"][sel], d["y2"][sel] / d["size2"][sel],
+                         d["x1"][mi] / d["size1"][mi], d["y1"][mi] / d["size1"][mi]], axis=1).astype(np.float32)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.ransac_homog_pairs(xyuv, seed=5)
+        t_pairs = (time.perf_counter() - t0) / reps
         t0 = time.perf_counter()
         n_in, Hh, idxh = run_host(lib, d, 5)
         t_cpu = time.perf_counter() - t0
         same = H is not None and np.array_equal(H.reshape(-1), Hh) and np.array_equal(idx, idxh)
         print(json.dumps({"matches": int((d["match"] >= 0).sum()), "outlier_share": out, "samples": iters,
-                          "consensus": int(len(idx)), "gpu_ms": round(t_gpu * 1e3, 3),
+                          "consensus": int(len(idx)), "gpu_ms": round(t_gpu * 1e3, 3), "gpu_pairs_ms": round(t_pairs * 1e3, 3),
                           "host_ms": round(t_cpu * 1e3, 3), "equal": bool(same)}), flush=True)
     ctx.close()
 
