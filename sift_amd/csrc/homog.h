@@ -48,19 +48,20 @@ SIFT_HD inline void dlt_rows(float x, float y, float u, float v, double* r0, dou
 // (|R_kk| <= 1e-12 |R_00|: repeated or collinear sample points).
 SIFT_HD inline int solve_lsq(double* M, int rows, double* h) {
     SIFT_NO_CONTRACT
-    // Every sweep below walks the matrix row by row (it is row-major) and keeps one
-    // running sum per column, so each sum still adds its terms in row order.
+    // Every sweep walks the matrix row by row (it is row-major) over all nine columns
+    // with one running sum per column, so each sum adds its terms in row order and the
+    // inner loops have a fixed length (columns already reduced carry values nobody reads).
     int perm[NCOL];
     for (int c = 0; c < NCOL; c++) perm[c] = c;
+    double cn[NAUG];  // squared column norms below the current row
+    for (int c = 0; c < NAUG; c++) cn[c] = 0.0;
+    for (int r = 0; r < rows; r++) {
+        const double* row = M + r * NAUG;
+        for (int c = 0; c < NAUG; c++) cn[c] += row[c] * row[c];
+    }
     double r00 = 0.0;
     for (int k = 0; k < NCOL; k++) {
         // pivot: the remaining column of largest norm below row k (first of equals)
-        double cn[NCOL];
-        for (int c = k; c < NCOL; c++) cn[c] = 0.0;
-        for (int r = k; r < rows; r++) {
-            const double* row = M + r * NAUG;
-            for (int c = k; c < NCOL; c++) cn[c] += row[c] * row[c];
-        }
         int best = k;
         for (int c = k + 1; c < NCOL; c++)
             if (cn[c] > cn[best]) best = c;
@@ -83,22 +84,24 @@ SIFT_HD inline int solve_lsq(double* M, int rows, double* h) {
         const double alpha = x0 >= 0.0 ? -norm : norm;
         const double v0 = x0 - alpha;
         const double vtv = v0 * v0 + (bn - x0 * x0);
-        if (vtv > 0.0) {
-            double dot[NAUG];
-            for (int c = k + 1; c < NAUG; c++) dot[c] = v0 * top[c];
-            for (int r = k + 1; r < rows; r++) {
-                const double* row = M + r * NAUG;
-                const double vk = row[k];
-                for (int c = k + 1; c < NAUG; c++) dot[c] += vk * row[c];
-            }
-            for (int c = k + 1; c < NAUG; c++) {
-                dot[c] = 2.0 * dot[c] / vtv;
-                top[c] -= dot[c] * v0;
-            }
-            for (int r = k + 1; r < rows; r++) {
-                double* row = M + r * NAUG;
-                const double vk = row[k];
-                for (int c = k + 1; c < NAUG; c++) row[c] -= dot[c] * vk;
+        double dot[NAUG];
+        for (int c = 0; c < NAUG; c++) dot[c] = v0 * top[c];
+        for (int r = k + 1; r < rows; r++) {
+            const double* row = M + r * NAUG;
+            const double vk = row[k];
+            for (int c = 0; c < NAUG; c++) dot[c] += vk * row[c];
+        }
+        for (int c = 0; c < NAUG; c++) dot[c] = vtv > 0.0 ? 2.0 * dot[c] / vtv : 0.0;
+        for (int c = k + 1; c < NAUG; c++) top[c] -= dot[c] * v0;
+        // apply the reflection to the rows below and gather the next step's column norms in the same sweep
+        for (int c = 0; c < NAUG; c++) cn[c] = 0.0;
+        for (int r = k + 1; r < rows; r++) {
+            double* row = M + r * NAUG;
+            const double vk = row[k];
+            for (int c = 0; c < NAUG; c++) {
+                const double t = row[c] - dot[c] * vk;
+                row[c] = t;
+                cn[c] += t * t;
             }
         }
         top[k] = alpha;
