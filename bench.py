@@ -226,6 +226,35 @@ def main():
             extras["blur_mode_1_ms_per_frame"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
             extras["blur_mode_1_features"] = int(nfast)
             ctx.extract_dev(d_frame, W, H, prm, out)  # back to the exact plan
+        # the consumers behind the matcher: RANSAC homography over planted matches (host pointers in,
+        # model out) and the two stitcher warps of an RGB frame of the workload's size (kernel time)
+        rng = np.random.default_rng(11)
+        nmt = 20000
+        Ht = np.array([0.98, 0.05, 40.0, -0.04, 1.02, 15.0, 1.5e-5, -1.0e-5, 1.0])
+        px, py = rng.uniform(20, W - 20, nmt), rng.uniform(20, H - 20, nmt)
+        den = Ht[6] * px + Ht[7] * py + Ht[8]
+        pu, pv = (Ht[0] * px + Ht[1] * py + Ht[2]) / den, (Ht[3] * px + Ht[4] * py + Ht[5]) / den
+        wrong = rng.random(nmt) < 0.4
+        pu, pv = np.where(wrong, rng.uniform(0, W, nmt), pu), np.where(wrong, rng.uniform(0, H, nmt), pv)
+        xyuv = np.stack([np.floor(px), np.floor(py), np.rint(pu), np.rint(pv)], axis=1).astype(np.float32)
+        ctx.ransac_homog_pairs(xyuv, seed=5)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            Hr, ridx, rit = ctx.ransac_homog_pairs(xyuv, seed=5)
+        extras["ransac_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        extras["ransac_case"] = "%d matches, 40 %% wrong, %d samples, consensus %d" % (nmt, rit, len(ridx))
+        rgb = rng.integers(1, 255, (H, W, 3)).astype(np.uint8)
+        canvas = np.zeros((int(H * 1.1), int(W * 1.6), 3), np.uint8)
+        Hw = np.array([1.01, 0.02, W * 0.25, -0.015, 0.99, 40.0, 2e-6, -1e-6, 1], np.float32)
+        ctx.warp_perspective(rgb, Hw, canvas)
+        ctx.warp_cylinder(rgb, float(W))
+        ctx.profile(True)
+        ctx.profile_read()
+        ctx.warp_perspective(rgb, Hw, canvas)
+        extras["warp_perspective_kernel_ms"] = round(ctx.profile_read()["warp"][0], 4)
+        ctx.warp_cylinder(rgb, float(W))
+        extras["warp_cylinder_kernel_ms"] = round(ctx.profile_read()["warp"][0], 4)
+        ctx.profile(False)
 
     # ---- match leg ---------------------------------------------------------------------
     match = None
