@@ -108,7 +108,13 @@ class DevMem:
     second runtime, e.g. torch's own copy, after the first has the device does not work)."""
 
     def __init__(self):
-        self.hip = C.CDLL("libamdhip64.so")
+        path = "libamdhip64.so"
+        with open("/proc/self/maps") as f:  # the copy libsift_hip.so brought in
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        self.hip = C.CDLL(path)
         self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipFree.argtypes = [C.c_void_p]
