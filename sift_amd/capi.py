@@ -97,6 +97,8 @@ def load_library() -> C.CDLL:
         "sift_hip_last_error": (C.c_char_p, [vp]),
         "sift_hip_stream": (vp, [vp]),
         "sift_hip_synchronize": (C.c_int, [vp]),
+        "sift_hip_host_alloc": (C.c_int, [vp, C.POINTER(C.c_void_p), C.c_size_t]),
+        "sift_hip_host_free": (C.c_int, [vp, vp]),
         "sift_hip_extract": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip, vp]),
         "sift_hip_extract_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, P, vp, C.c_int, ip, vp]),
         "sift_hip_extract_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, P, vp, C.c_int, ip]),
@@ -176,8 +178,26 @@ class SiftHip:
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.sift_hip_host_free(self.h, p)
+            self._pinned = []
             self.lib.sift_hip_destroy(self.h)
             self.h = None
+
+    def pinned_array(self, count: int, dtype) -> np.ndarray:
+        """`count` items of `dtype` in page-locked host memory (sift_hip_host_alloc): result copies
+        into it run by direct DMA.  The memory lives until close(); keep no views beyond that."""
+        dtype = np.dtype(dtype)
+        nbytes = max(1, count * dtype.itemsize)
+        p = C.c_void_p()
+        self._check(self.lib.sift_hip_host_alloc(self.h, C.byref(p), nbytes))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p)
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        a = np.frombuffer(buf, dtype=np.uint8)[: count * dtype.itemsize].view(dtype)
+        a[...] = np.zeros((), dtype)
+        return a
 
     def __del__(self):
         try:

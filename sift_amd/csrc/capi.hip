@@ -650,6 +650,24 @@ int sift_hip_synchronize(sift_hip_ctx* ctx) {
     return hip_ok(ctx, hipStreamSynchronize(ctx->stream), "synchronize") ? SIFT_HIP_OK : SIFT_HIP_ERR_HIP;
 }
 
+int sift_hip_host_alloc(sift_hip_ctx* ctx, void** ptr, size_t bytes) {
+    if (bad_ctx(ctx) || !ptr || bytes == 0) return SIFT_HIP_ERR_ARG;
+    *ptr = nullptr;
+    if (!hip_ok(ctx, hipSetDevice(ctx->device), "set device")) return SIFT_HIP_ERR_HIP;
+    if (hipHostMalloc(ptr, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return SIFT_HIP_ERR_NOMEM;
+    }
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_host_free(sift_hip_ctx* ctx, void* ptr) {
+    (void)ctx;  // the allocation does not belong to a context
+    if (!ptr) return SIFT_HIP_OK;
+    return hipHostFree(ptr) == hipSuccess ? SIFT_HIP_OK : SIFT_HIP_ERR_HIP;
+}
+
 int sift_hip_pyramid_octaves(int w, int h) {
     if (w <= 0 || h <= 0) return SIFT_HIP_ERR_ARG;
     return pyramid_octaves((size_t)w, (size_t)h);

@@ -158,12 +158,22 @@ void Sift::pyramid() {
     prm.octaves = sift_amd::options().octaves;
     prm.subpixel = sift_amd::options().subpixel;
     prm.blur_mode = sift_amd::options().blur_mode;
-    int cap = 1 << 15, n = 0;
-    std::vector<sift_hip_feat> buf;
+    // The records come back into a page-locked buffer kept for the process (direct DMA).
+    static sift_hip_feat* buf = nullptr;
+    static int buf_cap = 0;
+    int cap = buf_cap > 0 ? buf_cap : 1 << 15, n = 0;
     for (;;) {
-        buf.resize((size_t)cap);
+        if (cap > buf_cap) {
+            sift_hip_host_free(ctx, buf);
+            buf = nullptr;
+            buf_cap = 0;
+            void* p = nullptr;
+            check(ctx, sift_hip_host_alloc(ctx, &p, (size_t)cap * sizeof(sift_hip_feat)), "sift_hip_host_alloc");
+            buf = (sift_hip_feat*)p;
+            buf_cap = cap;
+        }
         const int rc = sift_hip_extract(ctx, raw_img.raw_img.data(), (int)raw_img.width, (int)raw_img.height,
-                                        raw_img.bitCount / 8, &prm, buf.data(), cap, &n, nullptr);
+                                        raw_img.bitCount / 8, &prm, buf, buf_cap, &n, nullptr);
         if (rc == SIFT_HIP_ERR_NOSPC) {
             cap = n;
             continue;

@@ -5,6 +5,8 @@ orientation bin, mm) and match indices/distances; descriptors within L2 1e-3 of
 the oracle's clamped histogram (hardware-rate atan2/exp/sqrt and fixed-point bin
 sums instead of sequential float additions), bytes within +-1.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -452,3 +454,20 @@ def test_two_contexts_extract_concurrently(sift):
     assert not any(t.is_alive() for t in ths), "concurrent contexts hang"
     other.close()
     assert got["a"].tobytes() == want.tobytes() and got["b"].tobytes() == want.tobytes()
+
+
+def test_page_locked_output_buffer(sift):
+    """sift_hip_host_alloc: the same features arrive in a page-locked array as in a pageable one."""
+    img = sift_amd.blob_image(320, 240, seed=11)
+    ref, _ = sift.extract(img)
+    out = sift.pinned_array(4096, sift_amd.FEAT_DTYPE)
+    n = C.c_int(0)
+    g = np.ascontiguousarray(img, np.float32)
+    prm = sift_amd.SiftParams()._c()
+    rc = sift.lib.sift_hip_extract(sift.h, C.c_void_p(g.ctypes.data), 320, 240, 1, C.byref(prm),
+                                   C.c_void_p(out.ctypes.data), len(out), C.byref(n), None)
+    assert rc == 0 and n.value == len(ref) and np.array_equal(out[: n.value], ref)
+    p = C.c_void_p()
+    assert sift.lib.sift_hip_host_alloc(sift.h, C.byref(p), 0) == sift_amd.capi.ERR_ARG
+    assert sift.lib.sift_hip_host_alloc(sift.h, None, 16) == sift_amd.capi.ERR_ARG
+    assert sift.lib.sift_hip_host_free(sift.h, None) == 0
