@@ -21,11 +21,12 @@ ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--octaves", type=int, default=4)
 ap.add_argument("--blur-mode", type=int, default=0)
 ap.add_argument("--match-n", type=int, default=0)
+ap.add_argument("--pinned", action="store_true", help="feature array in page-locked memory")
 a = ap.parse_args()
 ctx = sift_amd.SiftHip(0)
 frame = sift_amd.blob_image(a.width, a.height, seed=1)
 d = torch.from_numpy(frame).cuda()
-out = np.zeros(1 << 16, sift_amd.FEAT_DTYPE)
+out = ctx.pinned_array(1 << 16, sift_amd.FEAT_DTYPE) if a.pinned else np.zeros(1 << 16, sift_amd.FEAT_DTYPE)
 n = 0
 for _ in range(a.steps):
     n = ctx.extract_dev(d, a.width, a.height, SiftParams(octaves=a.octaves, blur_mode=a.blur_mode), out)
