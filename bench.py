@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--match-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pageable-out", action="store_true", help="feature array in ordinary host memory (A/B)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo + SIFT_BENCH_ONE_GPU=1: rehearsal of the multi-rank path on one GPU (collectives on the CPU)")
     args = ap.parse_args()
 
     import torch
@@ -63,11 +65,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if os.environ.get("SIFT_BENCH_ONE_GPU") == "1":
+        local_rank = 0  # rehearsal: every rank on the one GPU there is
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -77,7 +85,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -193,7 +201,7 @@ def main():
 
     # ---- side measurements (rank 0, outside the timed region; none of them is `value`) -------
     extras = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         extras = {}
         # the same frame handed over as a host buffer: upload over PCIe included
         t0 = time.perf_counter()
@@ -279,8 +287,13 @@ def main():
         d_d2 = torch.empty(nq_local, dtype=torch.int32, device=dev)
 
         def match_step():
-            if world > 1:
+            if world > 1 and args.backend == "nccl":
                 dist.all_gather_into_tensor(d_r, d_rl)   # RCCL over xGMI
+                torch.cuda.current_stream().synchronize()
+            elif world > 1:
+                parts = [torch.empty((n_all // world, 128), dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, d_rl.cpu())
+                d_r.copy_(torch.cat(parts).to(dev))
                 torch.cuda.current_stream().synchronize()
             else:
                 d_r.copy_(d_rl)
@@ -311,7 +324,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of the reference's algorithm), one thread ----
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests.oracle_lib import Oracle
 
         orc = Oracle()
