@@ -20,6 +20,34 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def frames_of_rank(nframes: int, world: int, rank: int) -> range:
+    """Frames are independent (every octave restarts from its own image, Sift.cpp:145-149):
+    frame k goes to rank k mod world; no collective on the extract path."""
+    return range(rank, nframes, world)
+
+
+def gather_feature_counts(counts_local: torch.Tensor, nframes: int, group=None) -> torch.Tensor:
+    """Host-side bookkeeping after a sharded batch: every rank's per-frame feature counts (int32,
+    in the order of frames_of_rank) -> the counts of all nframes frames in frame order, on every
+    rank.  The feature lists themselves stay where they were produced."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    out = torch.zeros(nframes, dtype=torch.int32)
+    if world == 1:
+        out[:] = counts_local.cpu()
+        return out
+    per = (nframes + world - 1) // world
+    padded = torch.full((per,), -1, dtype=torch.int32, device=counts_local.device)
+    padded[: counts_local.numel()] = counts_local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    for r in range(world):
+        idx = list(frames_of_rank(nframes, world, r))
+        out[idx] = parts[r][: len(idx)].cpu()
+    assert rank >= 0
+    return out
+
+
 def all_gather_refs(r_local: torch.Tensor, group=None) -> torch.Tensor:
     """Concatenates every rank's (n_i x 128) uint8 references in rank order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1

@@ -67,3 +67,29 @@ def test_shard_bounds_cover():
             assert segs[0][0] == 0 and segs[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
             assert max(e - b for b, e in segs) - min(e - b for b, e in segs) <= 1
+
+
+def _frames_worker(rank, world, port, nframes, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sift_amd.sharded import frames_of_rank, gather_feature_counts
+
+    mine = list(frames_of_rank(nframes, world, rank))
+    counts = torch.tensor([100 + 3 * k for k in mine], dtype=torch.int32)  # stands for the extract of frame k
+    allc = gather_feature_counts(counts, nframes)
+    np.save(os.path.join(outdir, f"c{rank}.npy"), allc.numpy())
+    dist.destroy_process_group()
+
+
+def test_frames_shard_round_robin_and_counts_gather(tmp_path):
+    from sift_amd.sharded import frames_of_rank
+
+    for n, w in ((1024, 8), (10, 4), (3, 8), (7, 2)):
+        seen = sorted(k for r in range(w) for k in frames_of_rank(n, w, r))
+        assert seen == list(range(n))
+        assert all(k % w == r for r in range(w) for k in frames_of_rank(n, w, r))
+    mp.spawn(_frames_worker, args=(2, 29533, 7, str(tmp_path)), nprocs=2, join=True)
+    want = np.array([100 + 3 * k for k in range(7)], np.int32)
+    for rank in range(2):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"c{rank}.npy")), want)
