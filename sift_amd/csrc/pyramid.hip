@@ -94,7 +94,8 @@ void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, in
     hipLaunchKernelGGL(first_kernel, grid, dim3(256), 0, st, src, w, h, ratio, dst, nw, nh);
 }
 
-constexpr int kMaxColLds = 64 * 1024;  // largest LDS tile a blur pass may request
+constexpr int kMaxColLds = 64 * 1024;   // largest LDS tile a blur pass requests without asking for more
+constexpr int kBigColLds = 150 * 1024;  // gfx950 lets a workgroup address 160 KB once the kernel opts in
 
 // ---- separable blur ----------------------------------------------------------------
 // P = outputs per thread along the filter direction: 8 for large octaves (one LDS
@@ -397,8 +398,18 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
         int TH = 16 * P;
         while (TH > 4 * P && (size_t)(TH + K - 1 + P) * 256 > 32 * 1024) TH >>= 1;
-        const size_t lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
-        if (lds <= (size_t)kMaxColLds) {
+        size_t lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
+        // Kernels of several hundred taps (deep octaves): a tile of up to 150 KB still beats
+        // sliding the window over global memory; taller tiles amortise the K-1 halo rows.
+        static bool big_ok = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&blur_col_kernel<ACC, P>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBigColLds) == hipSuccess;
+        }();
+        if (lds > (size_t)kMaxColLds && big_ok) {
+            while (TH < 16 * P && (size_t)(2 * TH + K - 1 + P) * 256 <= (size_t)kBigColLds) TH <<= 1;
+            lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
+        }
+        if (lds <= (size_t)(big_ok ? kBigColLds : kMaxColLds)) {
             dim3 grid((W + 63) / 64, (H + TH - 1) / TH);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC, P>), grid, dim3(256), lds, st, tmp, dst, W, H,
                                d_taps, K, TH);
