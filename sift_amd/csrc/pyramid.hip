@@ -409,6 +409,12 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
             while (TH < 16 * P && (size_t)(2 * TH + K - 1 + P) * 256 <= (size_t)kBigColLds) TH <<= 1;
             lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
         }
+        // Small images: a wave alone on its SIMD issues one vector instruction per ~16 cycles, so
+        // prefer shorter tiles until there are about four workgroups per compute unit.
+        while (TH > 4 * P && (size_t)((W + 63) / 64) * ((H + TH - 1) / TH) < 1024) {
+            TH >>= 1;
+            lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
+        }
         if (lds <= (size_t)(big_ok ? kBigColLds : kMaxColLds)) {
             dim3 grid((W + 63) / 64, (H + TH - 1) / TH);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_kernel<ACC, P>), grid, dim3(256), lds, st, tmp, dst, W, H,
