@@ -401,10 +401,13 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         size_t lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
         // Kernels of several hundred taps (deep octaves): a tile of up to 150 KB still beats
         // sliding the window over global memory; taller tiles amortise the K-1 halo rows.
-        static bool big_ok = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&blur_col_kernel<ACC, P>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBigColLds) == hipSuccess;
-        }();
+        // (the opt-in is per device: once for each device a context of this process runs on)
+        static signed char big_state[64] = {0};  // 0 = not asked yet, 1 = granted, -1 = refused
+        signed char& bs = big_state[ctx->device & 63];
+        if (bs == 0)
+            bs = hipFuncSetAttribute(reinterpret_cast<const void*>(&blur_col_kernel<ACC, P>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kBigColLds) == hipSuccess ? 1 : -1;
+        const bool big_ok = bs == 1;
         if (lds > (size_t)kMaxColLds && big_ok) {
             while (TH < 16 * P && (size_t)(2 * TH + K - 1 + P) * 256 <= (size_t)kBigColLds) TH <<= 1;
             lds = (size_t)(TH + K - 1 + P) * 64 * sizeof(float);
