@@ -90,3 +90,16 @@ def test_arguments(sift):
     assert lib.sift_hip_warp_cylinder(sift.h, vp(src.ctypes.data), 32, -1, 5.0, vp(dst.ctypes.data), None, None) == E.ERR_ARG
     # edges are optional
     assert lib.sift_hip_warp_cylinder(sift.h, vp(src.ctypes.data), 32, 16, 50.0, vp(dst.ctypes.data), None, None) == 0
+
+
+def test_golden_fixture(sift):
+    """The GPU against tests/golden/stitch_oracle.npz (oracle outputs; regression guard)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stitch_oracle.npz"))
+    assert np.array_equal(sift.warp_perspective(g["src"], g["Hw"], g["canvas"].copy()), g["warped"])
+    cyl, up, down = sift.warp_cylinder(g["src"], float(g["focal"]))
+    assert np.array_equal(cyl, g["cyl"]) and np.array_equal(up, g["cyl_up"]) and np.array_equal(down, g["cyl_down"])
+    H, idx, _ = sift.ransac_homog_pairs(g["xyuv"], seed=int(g["ransac_seed"]))
+    assert np.array_equal(idx, g["ransac_inliers"])
+    np.testing.assert_allclose(H.reshape(-1), g["ransac_H"], rtol=2e-4, atol=1e-6)

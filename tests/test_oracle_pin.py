@@ -15,6 +15,7 @@ import pytest
 from tests.oracle_lib import REF_SO, Oracle, Reference
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def bits(a):
@@ -185,3 +186,40 @@ def test_stitch_warp_restatement_sanity(oracle):
     assert np.array_equal(out[:39, 30], src[:39, 30])  # k = 1 on the axis
     assert up.shape == (60, 2) and up[30, 0] == 30.0 and down[30, 1] > up[30, 1]
     assert (out[:, 0] == 0).all()  # the outermost columns sample outside the image
+
+
+def test_stitch_golden_regression_guard(oracle):
+    """tests/golden/stitch_oracle.npz (made by oracle/make_golden_stitch.py from the oracles
+    themselves: a regression guard, not a pin to the reference): the RANSAC restatement, the
+    CPU ransac_xform of the product and the warp restatement still give these results."""
+    import ctypes as C
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ransac_oracle
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "stitch_oracle.npz"))
+    xyuv = g["xyuv"]
+    H, fin, in_min = ransac_oracle.ransac_xform(xyuv[:, :2], xyuv[:, 2:], 4, 0.005, 3.0, int(g["ransac_seed"]))
+    assert np.array_equal(fin, g["ransac_inliers"]) and in_min == int(g["ransac_in_min"])
+    np.testing.assert_allclose(H, g["ransac_H"], rtol=1e-6)
+    # the product's CPU implementation on the same pairs (integer coordinates, scale 1)
+    host = C.CDLL(os.path.join(ROOT, "sift_amd", "lib", "libsift_host.so"))
+    vp = C.c_void_p
+    host.sift_host_ransac.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float,
+                                      C.c_uint, vp, vp]
+    n = len(xyuv)
+    x2, y2 = xyuv[:, 0].astype(np.int32), xyuv[:, 1].astype(np.int32)
+    x1, y1 = xyuv[:, 2].astype(np.int32), xyuv[:, 3].astype(np.int32)
+    one = np.ones(n, np.float32)
+    match = np.arange(n, dtype=np.int32)
+    Hh = np.zeros(9, np.float32)
+    idx = np.full(n, -1, np.int32)
+    p = lambda a: a.ctypes.data  # noqa: E731
+    n_in = host.sift_host_ransac(p(x2), p(y2), p(one), n, p(x1), p(y1), p(one), n, p(match), 4, 0.005, 3.0,
+                                 int(g["ransac_seed"]), p(Hh), p(idx))
+    assert n_in == len(g["ransac_inliers"]) and np.array_equal(idx[:n_in], g["ransac_inliers"])
+    np.testing.assert_allclose(Hh, g["ransac_H"], rtol=2e-4, atol=1e-6)
+    assert np.array_equal(oracle.warp_perspective(g["src"], g["Hw"], g["canvas"]), g["warped"])
+    cyl, up, down = oracle.warp_cylinder(g["src"], float(g["focal"]))
+    assert np.array_equal(cyl, g["cyl"]) and np.array_equal(up, g["cyl_up"]) and np.array_equal(down, g["cyl_down"])
