@@ -16,15 +16,6 @@
 
 using namespace sifthip;
 
-// Contexts alive per device.  The two-stream extract orders its streams with
-// device-side event waits; when several contexts do that on one device at once,
-// their streams outnumber the hardware queues (4), share them, and the waits can
-// form a cycle that never resolves (observed: two contexts extracting from two
-// threads hang).  With more than one context alive on a device every extract
-// therefore stays on its context's main stream.
-#include <atomic>
-static std::atomic<int> g_live_contexts[64];
-
 namespace sifthip {
 
 bool hip_ok(sift_hip_ctx* ctx, hipError_t e, const char* what) {
@@ -89,33 +80,36 @@ void prof_begin(sift_hip_ctx* ctx, int cls, hipStream_t st) {
 void prof_end(sift_hip_ctx* ctx, hipStream_t st) { hipEventRecord(ctx->events.back().b, st); }
 
 // ---- host constants ------------------------------------------------------------
-// Gaus::gau_meth / Gaus::gau_matrix, imglib/imglib.cpp:120-155, same operand types.
-static float gau_meth(size_t r, float p) {
-    float two = 2.0;
-    float num = std::exp(-std::pow((double)r, (double)two) / (two * std::pow(p, two)));
-    num /= std::sqrt(two * 3.14159265358979323846) * p;
-    return num;
+// Gaus::gau_matrix / Gaus::gau_meth, imglib/imglib.cpp:120-155.  The taps decide
+// which pixels become keypoints, so every operation keeps the operand types of the
+// reference (they fix the roundings): the exponent's numerator and the division in
+// double, the 2*sigma^2 term in float, the result of exp stored as float, the
+// 1/(sqrt(2*pi)*sigma) factor applied as one double division rounded to float.
+static float gaussian_tap(int dist, float sigma) {
+    const float two = 2.0f;
+    const double dist_sq = std::pow((double)(size_t)dist, (double)two);
+    const float two_sigma_sq = two * std::pow(sigma, two);  // float overload of pow
+    float tap = (float)std::exp(-dist_sq / two_sigma_sq);
+    tap = (float)(tap / (std::sqrt(two * 3.14159265358979323846) * sigma));
+    return tap;
 }
 
-static std::vector<float> gau_matrix(float p, size_t mat_len) {
-    std::vector<float> g;
-    if (mat_len == 0) mat_len = (int)(std::round((p * 6 + 1))) | 1;
+// Tap count: round(6*sigma + 1) forced odd unless the caller fixes it.  The kernel
+// is built from its centre outwards; the normalising sum is a float that receives
+// the centre tap, then twice each further tap, in order of distance.
+static std::vector<float> gau_matrix(float sigma, size_t mat_len) {
+    if (mat_len == 0) mat_len = (int)(std::round((sigma * 6 + 1))) | 1;
     if (mat_len % 2 == 0) ++mat_len;
-    g.resize(mat_len);
-    float sum = 0;
-    for (int i = 0, j = (int)(mat_len / 2); j < (int)mat_len; ++i, ++j) {
-        float temp;
-        if (i) {
-            temp = gau_meth(i, p);
-            g[j] = temp;
-            g[mat_len - j - 1] = temp;
-            sum += temp += temp;
-        } else {
-            g[j] = gau_meth(i, p);
-            sum += g[j];
-        }
+    const int half = (int)(mat_len / 2);
+    std::vector<float> from_centre((size_t)half + 1);
+    float norm = 0;
+    for (int dist = 0; dist <= half; ++dist) {
+        const float tap = gaussian_tap(dist, sigma);
+        from_centre[dist] = tap;
+        norm += dist ? tap + tap : tap;
     }
-    for (auto& v : g) v /= sum;
+    std::vector<float> g(mat_len);
+    for (int k = 0; k < (int)mat_len; ++k) g[k] = from_centre[std::abs(k - half)] / norm;
     return g;
 }
 
@@ -213,27 +207,11 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
     return SIFT_HIP_OK;
 }
 
-// Stream + workspace of octave `oi`.  Lane 0 is the context's main stream; with
-// profiling on every lane uses it, so that kernel durations are not inflated by
-// other octaves' kernels sharing the GPU.
+// Workspace of octave `oi` (created on first use; the streams belong to the context).
 static int get_lane(sift_hip_ctx* ctx, int oi, OctWs** out) {
     while ((int)ctx->lanes.size() <= oi) {
         OctWs ws;
-        if (ctx->lanes.empty()) {
-            ws.stream = ctx->stream;
-        } else {
-            // the small octaves get the more urgent priority: they are short, latency-bound
-            // kernels that would otherwise queue behind octave 0's large grids
-            int lo = 0, hi = 0;
-            hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = most urgent
-            const int prio = ctx->side_priority == 0 ? 0 : hi;
-            if (hipStreamCreateWithPriority(&ws.stream, hipStreamNonBlocking, prio) != hipSuccess)
-                return SIFT_HIP_ERR_HIP;
-            ws.own_stream = true;
-        }
-        if (hipEventCreateWithFlags(&ws.ev_emit, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ws.ev_done, hipEventDisableTiming) != hipSuccess)
-            return SIFT_HIP_ERR_HIP;
+        ws.stream = ctx->stream;
         ctx->lanes.push_back(ws);
     }
     *out = &ctx->lanes[oi];
@@ -269,15 +247,25 @@ static int check_async(sift_hip_ctx* ctx, const char* what) {
 }
 
 // The whole of Sift::pyramid for one device-resident gray frame; results stay on
-// the device (ctx->feat / ctx->hist / counters).  No host synchronisation.  The
-// caller's prior work on ctx->stream (the frame upload) is ordered before every
-// octave; when this returns, ctx->stream is ordered after every octave.
+// the device (per-octave feature buffers, ctx->gcounters).  No device-side
+// synchronisation between streams anywhere: octave 0 runs on ctx->stream, the
+// other octaves on ctx->side_stream, every kernel depends only on its
+// predecessors in its own stream, and the host joins the two (wait_extract).  A
+// stream that waits on another stream's event parks a barrier packet in its
+// hardware queue; streams share the few hardware queues of a process, so such a
+// packet can sit in front of the very work that has to signal it -- the library
+// therefore never enqueues one, whatever else the process runs (other contexts,
+// torch, RCCL).
+// frame_state: 0 = the frame is complete in device memory, 1 = it is produced by
+// work already enqueued on ctx->stream (an upload, the gray conversion): the host
+// then waits for that work before it feeds the side stream.
 static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params& prm,
-                           int feat_cap, int cand_cap, bool want_hist) {
+                           int feat_cap, int cand_cap, bool want_hist, int frame_state) {
     int rc = build_plan(ctx, w, h, prm);
     if (rc) return rc;
     const Plan& pl = ctx->plan;
     const int noct = (int)pl.oct.size();
+    if (noct > G_MAX_OCT) return SIFT_HIP_ERR_LIMIT;
     if ((rc = ensure(ctx, ctx->gcounters, G_SLOTS * sizeof(int)))) return rc;
     // all allocation first: ensure() may synchronise, which must not happen between launches
     for (int oi = 0; oi < noct; oi++) {
@@ -308,21 +296,13 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
             if ((rc = ensure(ctx, ws->feat_sub, (size_t)std::max(1, feat_cap) * 3 * sizeof(float)))) return rc;
         }
     }
-    if (!hip_ok(ctx, hipMemsetAsync(ctx->gcounters.p, 0, G_SLOTS * sizeof(int), ctx->stream), "reset counters"))
-        return SIFT_HIP_ERR_HIP;
-    hipEventRecord(ctx->ev_start, ctx->stream);
     const float thr = (float)((double)prm.dx_thr / 2.0);
-    const bool serial = ctx->profiling || ctx->force_serial || noct < 2 || g_live_contexts[ctx->device & 63].load() > 1;
-    // Streams: octave 0 (75 % of the pixels) on the context's stream, the smaller
-    // octaves one after another on a second, lower-priority stream that fills the
-    // gaps.  No octave waits for another; the context's stream is ordered after
-    // the second one at the end.
-    const int nside = 1;  // one extra stream
-    auto stream_of = [&](int oi) -> hipStream_t {
-        if (serial || oi == 0) return ctx->stream;
-        return ctx->lanes[std::min(oi, nside)].stream;
-    };
-    for (int s = 1; s <= nside && s < noct && !serial; s++) hipStreamWaitEvent(ctx->lanes[s].stream, ctx->ev_start, 0);
+    // With profiling on (or SIFT_HIP_SERIAL=1) everything runs on the main stream, so that
+    // kernel durations are not inflated by another octave's kernels sharing the GPU.
+    const bool serial = ctx->profiling || ctx->force_serial || noct < 2;
+    auto stream_of = [&](int oi) -> hipStream_t { return (serial || oi == 0) ? ctx->stream : ctx->side_stream; };
+    if (frame_state == 1 && !serial) hipEventRecord(ctx->ev_start, ctx->stream);
+    ctx->side_busy = !serial;
     // Host launch order: octave 0's pyramid first (long kernels that keep the main stream busy),
     // then all of octave 1 so that the side stream starts early, then the rest of octave 0,
     // then the remaining octaves (within run-to-run noise of launching octave by octave on
@@ -330,7 +310,6 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     // Each octave's own launches stay in order on its stream.
     auto enqueue_part = [&](int oi, int part) -> int {  // part 0 = pyramid, 1 = detect ... describe
         OctWs& ws = ctx->lanes[oi];
-        const hipStream_t own = ws.stream;
         const hipStream_t st = stream_of(oi);
         ws.stream = st;
         const OctavePlan& oc = pl.oct[oi];
@@ -342,12 +321,13 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         // (a workgroup sweeps K+2 rows of K+2 inputs per candidate: beyond ~1000 taps, i.e. in
         // octaves of a few thousand pixels, building the level is cheaper)
         const bool lazy = !prm.subpixel && !ctx->full_top_level && top_K <= 1024;
+        ws.lazy_top = lazy;
         int r = SIFT_HIP_OK;
         if (part == 0) {
             r = run_octave_pyramid(ctx, ws, st, d_gray, oi, lazy ? 1 : 0);
         } else {
             const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
-            launch_detect(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap,
+            launch_detect(ctx, ws, oi, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap,
                           lazy ? (const float*)ctx->table.p + oc.tap_off[prm.intvls + 2] : nullptr, top_K);
             if (prm.subpixel) launch_refine(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, prm.contr_thr);
             launch_orient(ctx, ws, PX, oc.W, d_lc, (const float*)ctx->table.p);
@@ -362,10 +342,12 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
             launch_descr(ctx, ws, PX, oc.W, oc.H, (const float*)ctx->table.p, feat_cap,
                          want_hist ? (float*)ws.hist.p : nullptr, max_window);
         }
-        ws.stream = own;
         return r;
     };
     if ((rc = enqueue_part(0, 0))) return rc;
+    // the main stream has its first long kernels; now the frame must be there for the side stream
+    if (frame_state == 1 && !serial && !hip_ok(ctx, hipEventSynchronize(ctx->ev_start), "frame upload"))
+        return SIFT_HIP_ERR_HIP;
     if (noct > 1) {
         if ((rc = enqueue_part(1, 0))) return rc;
         if ((rc = enqueue_part(1, 1))) return rc;
@@ -375,23 +357,30 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         if ((rc = enqueue_part(oi, 0))) return rc;
         if ((rc = enqueue_part(oi, 1))) return rc;
     }
-    for (int s = 1; s <= nside && s < noct && !serial; s++) {
-        hipEventRecord(ctx->lanes[s].ev_done, ctx->lanes[s].stream);
-        hipStreamWaitEvent(ctx->stream, ctx->lanes[s].ev_done, 0);
-    }
     return check_async(ctx, "extract launch");
 }
 
-// Copies the counters back, then each octave's features (and histograms) to their
-// place in the caller's array: octave-major, as the reference appends them.
+// Waits (on the host) for the frame's work on the side stream, copies the counters
+// back, then each octave's features (and histograms) to their place in the caller's
+// array: octave-major, as the reference appends them.  *cand_overflow receives the
+// largest candidate count that did not fit the table (0 if all did).  A caller that
+// has already waited for both streams passes join_side = false and the stream the
+// copies should use.
 static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow,
-                          hipStream_t st = nullptr) {
+                          hipStream_t st = nullptr, bool join_side = true) {
     if (!st) st = ctx->stream;
+    if (join_side && ctx->side_busy && !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)"))
+        return SIFT_HIP_ERR_HIP;
     if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
                                     st), "read counters"))
         return SIFT_HIP_ERR_HIP;
     if (!hip_ok(ctx, hipStreamSynchronize(st), "extract")) return SIFT_HIP_ERR_HIP;
-    *cand_overflow = ctx->h_counters[G_CAND_OVERFLOW];
+    *cand_overflow = 0;
+    for (int oi = 0; oi < (int)ctx->plan.oct.size(); oi++) {
+        int found = ctx->h_counters[G_OCT_CAND + oi];
+        if (ctx->lanes[oi].lazy_top) found = std::max(found, ctx->h_counters[G_OCT_CAND_TOP + oi]);
+        if (found > ctx->cand_cap) *cand_overflow = std::max(*cand_overflow, found);
+    }
     if (*cand_overflow) return SIFT_HIP_OK;
     const int noct = (int)ctx->plan.oct.size();
     const bool with_sub = ctx->plan.prm.subpixel != 0;
@@ -438,14 +427,14 @@ static int checked_params(const sift_hip_params* params, int w, int h, sift_hip_
 }
 
 static int extract_dev_impl(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params* params,
-                            sift_hip_feat* out, int cap, int* n, float* hist) {
+                            sift_hip_feat* out, int cap, int* n, float* hist, int frame_state = 0) {
     sift_hip_params prm;
     int rc = checked_params(params, w, h, &prm);
     if (rc) return rc;
     int cand_cap = std::max(ctx->cand_cap, std::max(cap, 1 << 16));
     for (int attempt = 0; attempt < 4; attempt++) {
         ctx->cand_cap = cand_cap;
-        rc = enqueue_extract(ctx, d_gray, w, h, prm, cap, cand_cap, hist != nullptr);
+        rc = enqueue_extract(ctx, d_gray, w, h, prm, cap, cand_cap, hist != nullptr, frame_state);
         if (rc) return rc;
         int overflow = 0;
         rc = fetch_features(ctx, out, cap, n, hist, &overflow);
@@ -468,14 +457,15 @@ static void swap_output_sets(sift_hip_ctx* ctx) {
 // A batch of equal-sized frames, software-pipelined over the two output sets:
 // frame f's kernels are enqueued before frame f-1's counters and features are
 // copied back (on the copy stream), so the device never waits for the host
-// between frames.  frame_ptr(f) returns the device address of frame f after
-// ordering ctx->stream behind whatever produces it; enqueued(f) is called once
-// frame f's kernels are in the stream.  If a frame overflows the candidate table
+// between frames.  frame_ptr(f) returns the device address of frame f once the
+// frame is complete there (it waits on the host if it has to); fetched(f) is called
+// when frame f's kernels have finished and its features are on the host, i.e. when
+// whatever held frame f may be reused.  If a frame overflows the candidate table
 // the rest of the batch falls back to the one-frame-at-a-time path, which grows it;
 // reload(f) returns frame f's device address for that path (the pipelined uploads
 // may have reused its slot by then).
-template <typename FramePtr, typename Enqueued, typename Reload>
-static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Enqueued enqueued, Reload reload, int w, int h,
+template <typename FramePtr, typename Fetched, typename Reload>
+static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Fetched fetched, Reload reload, int w, int h,
                                    int nframes, const sift_hip_params* params, sift_hip_feat* out, int cap, int* n) {
     sift_hip_params prm;
     int rc = checked_params(params, w, h, &prm);
@@ -499,23 +489,25 @@ static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Enqueu
         n[f] = 0;
         const float* d = frame_ptr(f);
         swap_output_sets(ctx);  // frame f writes the set that frame f-2 has released
-        rc = enqueue_extract(ctx, d, w, h, prm, cap, cand_cap, false);
-        enqueued(f);
+        rc = enqueue_extract(ctx, d, w, h, prm, cap, cand_cap, false, 0);
         if (rc) {
             hipStreamSynchronize(ctx->stream);
             return rc;
         }
         hipEventRecord(ctx->ev_frame[f & 1], ctx->stream);
+        if (ctx->side_busy) hipEventRecord(ctx->ev_side[f & 1], ctx->side_stream);
         if (f >= 1) {
             swap_output_sets(ctx);  // look at frame f-1's set
-            // The host waits for frame f-1 (frame f keeps the device busy meanwhile), then
-            // copies on the copy stream.  No device-side wait between streams here: with
-            // more streams in the process than hardware queues (4), a stream waiting for
-            // an event of a stream that shares its queue never wakes up.
-            if (!hip_ok(ctx, hipEventSynchronize(ctx->ev_frame[(f - 1) & 1]), "batch frame")) return SIFT_HIP_ERR_HIP;
+            // The host waits for frame f-1 on both streams (frame f keeps the device busy
+            // meanwhile), then copies on the copy stream: no stream ever waits for another.
+            if (!hip_ok(ctx, hipEventSynchronize(ctx->ev_frame[(f - 1) & 1]), "batch frame") ||
+                (ctx->side_busy && !hip_ok(ctx, hipEventSynchronize(ctx->ev_side[(f - 1) & 1]), "batch frame (side)")))
+                return SIFT_HIP_ERR_HIP;
             int overflow = 0;
-            rc = fetch_features(ctx, out + (size_t)(f - 1) * cap, cap, &n[f - 1], nullptr, &overflow, ctx->copy_stream);
+            rc = fetch_features(ctx, out + (size_t)(f - 1) * cap, cap, &n[f - 1], nullptr, &overflow, ctx->copy_stream,
+                                false);
             swap_output_sets(ctx);
+            fetched(f - 1);
             if (overflow) {
                 hipStreamSynchronize(ctx->stream);
                 return plain_from(f - 1);
@@ -563,17 +555,24 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     if (const char* e = std::getenv("SIFT_HIP_SERIAL")) ctx->force_serial = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_FULL_TOP")) ctx->full_top_level = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
+    // the small octaves' stream gets the more urgent priority: their kernels are short and
+    // latency-bound and would otherwise queue behind octave 0's large grids
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // prio_hi = most urgent
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, ctx->side_priority == 0 ? 0 : prio_hi) !=
+            hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_frame[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_frame[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_side[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_side[1], hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counters, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counters_alt, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         sift_hip_destroy(ctx);
         return SIFT_HIP_ERR_HIP;
     }
-    g_live_contexts[device & 63].fetch_add(1);
     *out = ctx;
     return SIFT_HIP_OK;
 }
@@ -582,16 +581,13 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     if (!ctx) return SIFT_HIP_OK;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     for (OctWs& ws : ctx->lanes) {
-        if (ws.own_stream && ws.stream) hipStreamSynchronize(ws.stream);
         DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
                         &ws.cand_mm, &ws.cand_off, &ws.counters, &ws.feat, &ws.hist, &ws.cand_sub, &ws.feat_sub, &ws.feat_alt, &ws.feat_sub_alt, &ws.row_off2, &ws.cand2, &ws.counters2};
         for (DevBuf* b : wb)
             if (b->p) hipFree(b->p);
-        if (ws.ev_emit) hipEventDestroy(ws.ev_emit);
-        if (ws.ev_done) hipEventDestroy(ws.ev_done);
-        if (ws.own_stream && ws.stream) hipStreamDestroy(ws.stream);
     }
     DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->table, &ctx->layer_consts,
                       &ctx->gcounters, &ctx->gcounters_alt, &ctx->gathered, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
@@ -607,11 +603,12 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     if (ctx->h_counters_alt) hipHostFree(ctx->h_counters_alt);
     for (hipEvent_t e : ctx->ev_frame) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_side) if (e) hipEventDestroy(e);
     for (auto& e : ctx->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->free_events) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
-    g_live_contexts[ctx->device & 63].fetch_sub(1);
     delete ctx;
     return SIFT_HIP_OK;
 }
@@ -685,7 +682,10 @@ int sift_hip_extract_dev(sift_hip_ctx* ctx, const float* d_gray, int w, int h, c
                          sift_hip_feat* out, int cap, int* n, float* hist) {
     if (bad_ctx(ctx) || !d_gray || w < 2 || h < 2 || !n || cap < 0 || (cap > 0 && !out)) return SIFT_HIP_ERR_ARG;
     *n = 0;
-    return extract_dev_impl(ctx, d_gray, w, h, params, out, cap, n, hist);
+    // the frame may come from work the caller enqueued on the context's stream
+    const int frame_state = hipStreamQuery(ctx->stream) == hipSuccess ? 0 : 1;
+    (void)hipGetLastError();  // hipErrorNotReady is not a failure
+    return extract_dev_impl(ctx, d_gray, w, h, params, out, cap, n, hist, frame_state);
 }
 
 int sift_hip_extract(sift_hip_ctx* ctx, const float* img, int w, int h, int channels, const sift_hip_params* params,
@@ -709,7 +709,7 @@ int sift_hip_extract(sift_hip_ctx* ctx, const float* img, int w, int h, int chan
         if (!hip_ok(ctx, hipMemcpyAsync(ctx->in_img.p, img, px * 4, hipMemcpyHostToDevice, ctx->stream), "upload"))
             return SIFT_HIP_ERR_HIP;
     }
-    return extract_dev_impl(ctx, (const float*)ctx->in_img.p, w, h, params, out, cap, n, hist);
+    return extract_dev_impl(ctx, (const float*)ctx->in_img.p, w, h, params, out, cap, n, hist, /*frame_state=*/1);
 }
 
 int sift_hip_extract_batch_dev(sift_hip_ctx* ctx, const float* d_frames, int w, int h, int nframes,
@@ -717,6 +717,8 @@ int sift_hip_extract_batch_dev(sift_hip_ctx* ctx, const float* d_frames, int w, 
     if (bad_ctx(ctx) || !d_frames || w < 2 || h < 2 || nframes < 0 || !n || cap < 0 || (cap > 0 && !out))
         return SIFT_HIP_ERR_ARG;
     const size_t px = (size_t)w * h;
+    // frames produced by work the caller enqueued on the context's stream: wait for it once
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "batch frames")) return SIFT_HIP_ERR_HIP;
     return extract_batch_pipelined(
         ctx, [&](int f) { return d_frames + (size_t)f * px; }, [](int) {},
         [&](int f) { return d_frames + (size_t)f * px; }, w, h, nframes, params, out, cap, n);
@@ -735,35 +737,37 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
     if ((rc = ensure(ctx, ctx->in_img, px * 4))) return rc;
     if ((rc = ensure(ctx, ctx->frame2, px * 4))) return rc;
     float* slot[2] = {(float*)ctx->in_img.p, (float*)ctx->frame2.p};
-    hipEvent_t up[2], done[2];
-    for (int i = 0; i < 2; i++) { hipEventCreateWithFlags(&up[i], hipEventDisableTiming); hipEventCreateWithFlags(&done[i], hipEventDisableTiming); }
-    // frame f+1 is uploaded on the copy stream while frame f's kernels run
-    if (nframes > 0) {
-        hipMemcpyAsync(slot[0], frames, px * 4, hipMemcpyHostToDevice, ctx->copy_stream);
-        hipEventRecord(up[0], ctx->copy_stream);
-    }
-    auto frame_ptr = [&](int f) -> const float* {
-        const int s = f & 1;
-        if (f + 1 < nframes) {
-            if (f >= 1) hipStreamWaitEvent(ctx->copy_stream, done[s ^ 1], 0);  // slot free again
-            hipMemcpyAsync(slot[s ^ 1], frames + (size_t)(f + 1) * px, px * 4, hipMemcpyHostToDevice, ctx->copy_stream);
-            hipEventRecord(up[s ^ 1], ctx->copy_stream);
-        }
-        hipStreamWaitEvent(ctx->stream, up[s], 0);
-        return slot[s];
+    hipEvent_t up[2];
+    for (int i = 0; i < 2; i++) hipEventCreateWithFlags(&up[i], hipEventDisableTiming);
+    // Frame f lives in slot f & 1.  Uploads run on the copy stream while earlier frames'
+    // kernels run; all ordering between the streams is done by the host: it waits for
+    // frame f's upload before enqueueing frame f's kernels, and starts the upload of
+    // frame f+2 into frame f's slot only when frame f's kernels have finished.
+    auto upload = [&](int f) {
+        hipMemcpyAsync(slot[f & 1], frames + (size_t)f * px, px * 4, hipMemcpyHostToDevice, ctx->copy_stream);
+        hipEventRecord(up[f & 1], ctx->copy_stream);
     };
-    auto enqueued = [&](int f) { hipEventRecord(done[f & 1], ctx->stream); };
+    for (int f = 0; f < std::min(nframes, 2); f++) upload(f);
+    auto frame_ptr = [&](int f) -> const float* {
+        hipEventSynchronize(up[f & 1]);
+        return slot[f & 1];
+    };
+    auto fetched = [&](int f) {
+        if (f + 2 < nframes) upload(f + 2);
+    };
     auto reload = [&](int f) -> const float* {
         hipStreamSynchronize(ctx->copy_stream);
         hipStreamSynchronize(ctx->stream);
+        hipStreamSynchronize(ctx->side_stream);
         if (!hip_ok(ctx, hipMemcpy(slot[0], frames + (size_t)f * px, px * 4, hipMemcpyHostToDevice), "upload frame"))
             return nullptr;
         return slot[0];
     };
-    const int worst = extract_batch_pipelined(ctx, frame_ptr, enqueued, reload, w, h, nframes, params, out, cap, n);
+    const int worst = extract_batch_pipelined(ctx, frame_ptr, fetched, reload, w, h, nframes, params, out, cap, n);
     hipStreamSynchronize(ctx->copy_stream);
     hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 2; i++) { hipEventDestroy(up[i]); hipEventDestroy(done[i]); }
+    hipStreamSynchronize(ctx->side_stream);
+    for (int i = 0; i < 2; i++) hipEventDestroy(up[i]);
     return worst;
 }
 

@@ -192,7 +192,7 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* s_warp, int& tot
 
 __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__ row_cnt, int* __restrict__ row_off,
                                                          int nrows, int cand_cap, int* __restrict__ counters,
-                                                         int* __restrict__ gcounters) {
+                                                         int* __restrict__ found_slot) {
     __shared__ int s_warp[40];
     // thread t owns the rows [t*C, (t+1)*C): one workgroup scan for any row count
     const int C = (nrows + 1023) / 1024;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void scan_rows_kernel(const int* __restrict__
     if (threadIdx.x == 0) {
         counters[CNT_NCAND_TOTAL] = total;
         counters[CNT_NCAND] = min(total, cand_cap);
-        if (total > cand_cap) atomicMax(&gcounters[G_CAND_OVERFLOW], total);
+        *found_slot = total;  // written on every frame; the host compares it with the table size
     }
 }
 
@@ -702,8 +702,8 @@ __global__ __launch_bounds__(256) void emit_kernel(const Cand* __restrict__ cand
     }
 }
 
-void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
-                   float thr, int cand_cap, const float* d_top_taps, int top_K) {
+void launch_detect(sift_hip_ctx* ctx, OctWs& ws, int octave, size_t PX, int W, int H, int intvls,
+                   const LayerConsts* d_lc, float thr, int cand_cap, const float* d_top_taps, int top_K) {
     const int WW = (W + 63) / 64;
     const int nrows = intvls * H;
     const int lazy = d_top_taps != nullptr;
@@ -722,7 +722,8 @@ void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
             unsigned long long* masks_top = (unsigned long long*)ws.masks.p + (size_t)top * H * WW;
             int* row_cnt_top = (int*)ws.row_cnt.p + (size_t)top * H;
             hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, ws.stream, (const int*)row_cnt_top,
-                               (int*)ws.row_off2.p, H, cand_cap, (int*)ws.counters2.p, (int*)ctx->gcounters.p);
+                               (int*)ws.row_off2.p, H, cand_cap, (int*)ws.counters2.p,
+                               (int*)ctx->gcounters.p + G_OCT_CAND_TOP + octave);
             hipLaunchKernelGGL(expand_rows_kernel, dim3(H), dim3(64), 0, ws.stream, (const unsigned long long*)masks_top,
                                (const int*)row_cnt_top, (const int*)ws.row_off2.p, H, WW, (Cand*)ws.cand2.p, cand_cap);
             const float* g_lo = (const float*)ws.gau_all.p + (size_t)intvls * PX;
@@ -736,7 +737,8 @@ void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
     {
         ProfScope ps(ctx, SIFT_HIP_K_COMPACT, ws.stream);
         hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(1024), 0, ws.stream, (const int*)ws.row_cnt.p,
-                           (int*)ws.row_off.p, nrows, cand_cap, (int*)ws.counters.p, (int*)ctx->gcounters.p);
+                           (int*)ws.row_off.p, nrows, cand_cap, (int*)ws.counters.p,
+                           (int*)ctx->gcounters.p + G_OCT_CAND + octave);
         hipLaunchKernelGGL(expand_rows_kernel, dim3(nrows), dim3(64), 0, ws.stream,
                            (const unsigned long long*)ws.masks.p, (const int*)ws.row_cnt.p, (const int*)ws.row_off.p,
                            H, WW, (Cand*)ws.cand.p, cand_cap);

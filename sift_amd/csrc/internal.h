@@ -24,10 +24,15 @@ enum Counter {
     CNT_SLOTS = 8
 };
 // Slots of the per-context (all octaves) counter block.
+// Every slot an octave owns is written unconditionally by that octave's kernels on
+// every frame, so the block is never cleared: no stream has to wait for another
+// stream's reset before it may start.
 enum GlobalCounter {
-    G_CAND_OVERFLOW = 0,  // largest candidate count that did not fit, 0 if all fit
-    G_OCT_FEATS = 1,      // G_OCT_FEATS + o: features found in octave o (may exceed the capacity)
-    G_SLOTS = 32
+    G_MAX_OCT = 32,
+    G_OCT_FEATS = 0,             // + o: features found in octave o (may exceed the capacity)
+    G_OCT_CAND = G_MAX_OCT,      // + o: candidates found in octave o (may exceed the candidate table)
+    G_OCT_CAND_TOP = 2 * G_MAX_OCT,  // + o: tentative top-layer candidates of octave o (same table size)
+    G_SLOTS = 3 * G_MAX_OCT
 };
 
 struct DevBuf {
@@ -40,9 +45,8 @@ struct DevBuf {
 // on one of a few HIP streams; the octave-major output order of the reference is
 // restored by the order of the device-to-host copies.
 struct OctWs {
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t ev_emit = nullptr, ev_done = nullptr;
+    hipStream_t stream = nullptr;  // where this octave's launches go during the current enqueue (not owned)
+    bool lazy_top = false;         // the current frame evaluates the last Gaussian level only at top-layer extrema
     DevBuf base, tmp, gau_all, masks, row_cnt, row_off, cand, cand_mask, cand_mm, cand_off, counters, feat, hist;
     DevBuf cand_sub, feat_sub;  // sub-pixel offsets per candidate (float4) / per feature (3 floats)
     DevBuf row_off2, cand2, counters2;  // tentative top-layer candidates (the last level is built only there)
@@ -78,7 +82,9 @@ struct Plan {
 struct sift_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;  // octaves >= 1 of a frame (urgent priority); never waits on another stream
     hipStream_t copy_stream = nullptr;
+    bool side_busy = false;             // the last enqueue put work on side_stream
     std::string last_error;
 
     sifthip::Plan plan;
@@ -95,7 +101,8 @@ struct sift_hip_ctx {
     sifthip::DevBuf gathered;  // all ranks' reference descriptors (sharded match)
     sifthip::RansacWs ransac;
     sifthip::DevBuf warp_src, warp_dst, warp_edges;
-    hipEvent_t ev_frame[2] = {nullptr, nullptr};
+    hipEvent_t ev_frame[2] = {nullptr, nullptr};  // end of a batch frame's work on `stream` ...
+    hipEvent_t ev_side[2] = {nullptr, nullptr};   // ... and on `side_stream`
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
 
@@ -146,8 +153,8 @@ struct LayerConsts {  // per DoG layer 1..intvls of one octave
 };
 // ws.gau_all: level-major Gaussian images of the octave, PX pixels per level
 // (DoG values are recomputed from adjacent levels, never stored).
-void launch_detect(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
-                   float thr, int cand_cap, const float* d_top_taps, int top_K);
+void launch_detect(sift_hip_ctx* ctx, OctWs& ws, int octave, size_t PX, int W, int H, int intvls,
+                   const LayerConsts* d_lc, float thr, int cand_cap, const float* d_top_taps, int top_K);
 void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int intvls, const LayerConsts* d_lc,
                    float contr_thr);
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table);

@@ -76,12 +76,26 @@ def test_4k_extract_is_deterministic_ordered_and_in_bounds(sift, frame4k):
     assert set(np.unique(f1["size"])) <= {2.0, 1.0, 0.5, 0.25}
 
 
-@pytest.mark.parametrize("octave", [1, 2, 3])
+@pytest.mark.parametrize("octave", [0, 1, 2, 3])
 def test_4k_pyramid_octaves_bit_exact(sift, oracle, frame4k, octave):
+    # octave 0 = 7680 x 4320 (75 % of the frame's pixels; the only place the
+    # 8-outputs-per-thread kernels run over 7680-pixel rows): about half a minute of oracle time
     g, d = sift.octave_levels(frame4k, octave)
     go, do = oracle.octave_levels(frame4k, octave)
     assert np.array_equal(bits(g), bits(go))
+    del go
     assert np.array_equal(bits(d), bits(do))
+
+
+def test_1080p_octave0_features_equal_oracle(sift, oracle):
+    # One octave only: the doubled 1080p frame (3840 x 2160) is large enough for the kernels
+    # that octave 0 of the 4K frame uses (8 outputs per thread, 16-row detect tiles), and the
+    # oracle redoes the whole of it -- blur, detect, orientation, descriptors -- record for record.
+    img = sift_amd.blob_image(1920, 1080, seed=21)
+    f, h = sift.extract(img, SiftParams(octaves=1), cap=1 << 16, want_hist=True)
+    fo, ho = oracle.extract(img, octaves=1)
+    assert len(fo) > 3000 and (fo["size"] == 2.0).all()
+    compare_records(f, h, fo, ho)
 
 
 def test_4k_octave1_features_equal_oracle_on_a_crop(sift, oracle, frame4k):

@@ -434,19 +434,24 @@ def test_blur_and_resample_random_shapes(sift, oracle):
 
 
 def test_two_contexts_extract_concurrently(sift):
-    """Two contexts on one device driven from two threads: each falls back to its main
-    stream (their event-ordered stream pairs would outnumber the hardware queues and
-    can wait on each other forever) and both give the single-context result."""
+    """Two contexts on one device driven from two threads: each keeps its two streams (the
+    library joins them on the host, no stream waits on another's event) and both give the
+    single-context result; then the same with the batch entry point (uploads on a third
+    stream per context)."""
     import threading
 
     img = sift_amd.blob_image(640, 480, seed=8)
     want, _ = sift.extract(img)
+    frames = np.stack([img, sift_amd.blob_image(640, 480, seed=9), img])
+    want_b, want_n = sift.extract_batch(frames, cap=4096)
     other = sift_amd.SiftHip(0)
     got = {}
 
     def work(name, ctx):
         for _ in range(6):
             got[name], _ = ctx.extract(img)
+        for _ in range(3):
+            got[name + "_batch"] = ctx.extract_batch(frames, cap=4096)
 
     ths = [threading.Thread(target=work, args=("a", sift)), threading.Thread(target=work, args=("b", other))]
     [t.start() for t in ths]
@@ -454,6 +459,12 @@ def test_two_contexts_extract_concurrently(sift):
     assert not any(t.is_alive() for t in ths), "concurrent contexts hang"
     other.close()
     assert got["a"].tobytes() == want.tobytes() and got["b"].tobytes() == want.tobytes()
+    for name in ("a_batch", "b_batch"):
+        fb, nb = got[name]
+        assert np.array_equal(nb, want_n)
+        for f in range(len(frames)):
+            assert fb[f, : nb[f]].tobytes() == want_b[f, : want_n[f]].tobytes()
+    assert want_b[0, : want_n[0]].tobytes() == want.tobytes()
 
 
 def test_page_locked_output_buffer(sift):
