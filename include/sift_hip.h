@@ -153,6 +153,19 @@ int sift_hip_match_u8(sift_hip_ctx* ctx, const uint8_t* q, int nq, const uint8_t
 int sift_hip_match_u8_dev(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
                           int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
 
+/* The same as sift_hip_match_u8_dev for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in
+ * the reference.  The call allocates nothing, on the device or through any library: its work
+ * areas (int8 copies of both sets, norms) live in a static device array of the library
+ * (about 17 MB per GPU, held until the process ends), which bounds the sizes: nq and nr at
+ * most SIFT_HIP_NOALLOC_MAX each, beyond which the call returns SIFT_HIP_ERR_LIMIT and
+ * launches nothing.  All calls on one GPU, from any context, share that array: calls that
+ * overlap in time on one GPU race and must be serialised by the caller.  Results are equal
+ * to sift_hip_match_u8_dev's bit for bit.  Runs on the context's stream, no host sync. */
+#define SIFT_HIP_NOALLOC_MAX 65536
+int sift_hip_match_u8_noalloc(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
+                              int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
+
 /* Multi-GPU form, one process per GPU: every rank passes its own shard of the references
  * (the same nr_local on every rank) and its own queries; the shards are all-gathered with
  * ncclAllGather on the caller's communicator (comm: an ncclComm_t of nranks ranks; RCCL over

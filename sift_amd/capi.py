@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
         "sift_hip_pyramid_octaves": (C.c_int, [C.c_int, C.c_int]),
         "sift_hip_match_u8": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_match_u8_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+        "sift_hip_match_u8_noalloc": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_match_u8_sharded": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_ransac_homog": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_uint,
                                             vp, vp, ip, ip]),
@@ -324,6 +325,12 @@ class SiftHip:
     def match_u8_dev(self, d_q, nq: int, d_r, nr: int, ratio: float, ratio_form: int, d_best, d_d1=None, d_d2=None):
         self._check(self.lib.sift_hip_match_u8_dev(self.h, _ptr(d_q), nq, _ptr(d_r), nr, ratio, ratio_form,
                                                    _ptr(d_best), _ptr(d_d1), _ptr(d_d2)))
+
+    def match_u8_noalloc(self, d_q, nq: int, d_r, nr: int, ratio: float, ratio_form: int, d_best, d_d1=None,
+                         d_d2=None):
+        """sift_hip_match_u8_noalloc: device pointers, no allocation inside the call, sizes bounded."""
+        self._check(self.lib.sift_hip_match_u8_noalloc(self.h, _ptr(d_q), nq, _ptr(d_r), nr, ratio, ratio_form,
+                                                       _ptr(d_best), _ptr(d_d1), _ptr(d_d2)))
 
     # ---- RANSAC homography over the matches ------------------------------------------
     def ransac_homog(self, q_feats: np.ndarray, r_feats: np.ndarray, best: np.ndarray, m: int = 4,

@@ -573,6 +573,10 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
         sift_hip_destroy(ctx);
         return SIFT_HIP_ERR_HIP;
     }
+    if (match_scratch_init(ctx) != SIFT_HIP_OK) {  // the device is current: once per device
+        sift_hip_destroy(ctx);
+        return SIFT_HIP_ERR_HIP;
+    }
     *out = ctx;
     return SIFT_HIP_OK;
 }
@@ -856,6 +860,16 @@ int sift_hip_match_u8_dev(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const u
     if (ratio_form != 0 && ratio_form != 1) return SIFT_HIP_ERR_ARG;
     if (nq == 0) return SIFT_HIP_OK;
     int rc = run_match(ctx, d_q, nq, d_r, nr, ratio, ratio_form, d_best, d_d1, d_d2);
+    if (rc) return rc;
+    return check_async(ctx, "match launch");
+}
+
+int sift_hip_match_u8_noalloc(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
+                              int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
+    if (bad_ctx(ctx) || nq < 0 || nr < 0 || (nq > 0 && (!d_q || !d_best)) || (nr > 0 && !d_r)) return SIFT_HIP_ERR_ARG;
+    if (ratio_form != 0 && ratio_form != 1) return SIFT_HIP_ERR_ARG;
+    if (nq == 0) return SIFT_HIP_OK;
+    int rc = run_match_noalloc(ctx, d_q, nq, d_r, nr, ratio, ratio_form, d_best, d_d1, d_d2);
     if (rc) return rc;
     return check_async(ctx, "match launch");
 }

@@ -99,6 +99,7 @@ struct sift_hip_ctx {
     int32_t* h_counters_alt = nullptr;  // ... and the other set's
     sifthip::DevBuf gcounters_alt;
     sifthip::DevBuf gathered;  // all ranks' reference descriptors (sharded match)
+    unsigned char* match_scratch = nullptr;  // this device's copy of the matcher's static work area (not owned)
     sifthip::RansacWs ransac;
     sifthip::DevBuf warp_src, warp_dst, warp_edges;
     hipEvent_t ev_frame[2] = {nullptr, nullptr};  // end of a batch frame's work on `stream` ...
@@ -166,6 +167,11 @@ void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const f
 // match.hip
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
               int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
+// The same launches with the work areas in the library's static device array (no allocation);
+// match_scratch_init looks that array's address up for ctx->device (which must be current).
+int match_scratch_init(sift_hip_ctx* ctx);
+int run_match_noalloc(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
+                      int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
 
 // warp.hip
 void launch_warp_perspective(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_src, int s_col, int s_row,

@@ -16,6 +16,8 @@
 // reached only by tiles that pass a max-over-tile threshold test (see match_kernel).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <string>
 
 #include "internal.h"
 
@@ -323,10 +325,36 @@ __global__ __launch_bounds__(256) void match_kernel(const int8_t* __restrict__ q
     }
 }
 
-int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio, int ratio_form,
-              int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
+// Launch sequence shared by both entry-point families: the int8 copies, norms and
+// per-reference constants go to the four work areas the caller names.
+static void launch_match(hipStream_t st, bool big, const uint8_t* d_q, int nq, int nq_pad, const uint8_t* d_r, int nr,
+                         int nr_pad, int8_t* qi8, int* qnorm, int8_t* ri8, int* rconst, float ratio, int ratio_form,
+                         int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
+    const int qpb = big ? 512 : 256;
+    hipLaunchKernelGGL(match_prep_kernel, dim3((nq_pad * 8 + 255) / 256), dim3(256), 0, st, d_q, nq, nq_pad, qi8, qnorm,
+                       0);
+    if (nr_pad > 0)
+        hipLaunchKernelGGL(match_prep_kernel, dim3((nr_pad * 8 + 255) / 256), dim3(256), 0, st, d_r, nr, nr_pad, ri8,
+                           rconst, 1);
+    if (big)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(match_kernel<4>), dim3(nq_pad / qpb), dim3(256), 0, st, (const int8_t*)qi8,
+                           (const int*)qnorm, nq, (const int8_t*)ri8, (const int*)rconst, nr, nr_pad, ratio,
+                           ratio_form, d_best, d_d1, d_d2);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(match_kernel<2>), dim3(nq_pad / qpb), dim3(256), 0, st, (const int8_t*)qi8,
+                           (const int*)qnorm, nq, (const int8_t*)ri8, (const int*)rconst, nr, nr_pad, ratio,
+                           ratio_form, d_best, d_d1, d_d2);
+}
+
+static bool match_big(int nq) {
     bool big = nq >= 512 * 512;  // >= 2 workgroups of 512 queries per CU
     if (const char* e = std::getenv("SIFT_MATCH_NB")) big = (e[0] == '4');
+    return big;
+}
+
+int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio, int ratio_form,
+              int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
+    const bool big = match_big(nq);
     const int qpb = big ? 512 : 256;
     const int nq_pad = (nq + qpb - 1) / qpb * qpb;
     const int nr_pad = (nr + RT - 1) / RT * RT;
@@ -336,19 +364,61 @@ int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r,
     if ((rc = ensure(ctx, ctx->qnorm, (size_t)nq_pad * 4))) return rc;
     if ((rc = ensure(ctx, ctx->rconst, (size_t)std::max(nr_pad, RT) * 8))) return rc;
     ProfScope ps(ctx, SIFT_HIP_K_MATCH, ctx->stream);
-    hipLaunchKernelGGL(match_prep_kernel, dim3((nq_pad * 8 + 255) / 256), dim3(256), 0, ctx->stream, d_q, nq, nq_pad,
-                       (int8_t*)ctx->qi8.p, (int*)ctx->qnorm.p, 0);
-    if (nr_pad > 0)
-        hipLaunchKernelGGL(match_prep_kernel, dim3((nr_pad * 8 + 255) / 256), dim3(256), 0, ctx->stream, d_r, nr,
-                           nr_pad, (int8_t*)ctx->ri8.p, (int*)ctx->rconst.p, 1);
-    if (big)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(match_kernel<4>), dim3(nq_pad / qpb), dim3(256), 0, ctx->stream,
-                           (const int8_t*)ctx->qi8.p, (const int*)ctx->qnorm.p, nq, (const int8_t*)ctx->ri8.p,
-                           (const int*)ctx->rconst.p, nr, nr_pad, ratio, ratio_form, d_best, d_d1, d_d2);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(match_kernel<2>), dim3(nq_pad / qpb), dim3(256), 0, ctx->stream,
-                           (const int8_t*)ctx->qi8.p, (const int*)ctx->qnorm.p, nq, (const int8_t*)ctx->ri8.p,
-                           (const int*)ctx->rconst.p, nr, nr_pad, ratio, ratio_form, d_best, d_d1, d_d2);
+    launch_match(ctx->stream, big, d_q, nq, nq_pad, d_r, nr, nr_pad, (int8_t*)ctx->qi8.p, (int*)ctx->qnorm.p,
+                 (int8_t*)ctx->ri8.p, (int*)ctx->rconst.p, ratio, ratio_form, d_best, d_d1, d_d2);
+    return SIFT_HIP_OK;
+}
+
+// ---- the matcher for callers that cannot allocate ---------------------------------
+// Its work areas (int8 copies of both descriptor sets, query norms, reference
+// constants) live in one file-scope device array instead of buffers of the context.
+// Each GPU holds its own copy of the array at its own address; `scratch` itself is
+// only the host-side handle of the symbol, so the address is asked for once per
+// device (match_scratch_init, with that device current) and only that pointer is
+// ever handed to kernels.
+constexpr int kNoAllocMax = SIFT_HIP_NOALLOC_MAX;                      // rows per side (a multiple of 512)
+constexpr size_t kScrQ = 0;                                            // int8 queries
+constexpr size_t kScrR = kScrQ + (size_t)kNoAllocMax * 128;            // int8 references
+constexpr size_t kScrQn = kScrR + (size_t)kNoAllocMax * 128;           // query norms
+constexpr size_t kScrRc = kScrQn + (size_t)kNoAllocMax * 4;            // reference constants (two ints per row)
+constexpr size_t kScrBytes = kScrRc + (size_t)kNoAllocMax * 8;
+static_assert(kNoAllocMax % 512 == 0 && kNoAllocMax >= RT, "padding must stay inside the array");
+static __device__ __align__(256) unsigned char scratch[kScrBytes];
+
+static unsigned char* g_scratch_ptr[64];  // per device: address of that device's copy of `scratch`
+static std::mutex g_scratch_mutex;
+
+int match_scratch_init(sift_hip_ctx* ctx) {
+    const int dev = ctx->device;
+    if (dev < 0 || dev >= 64) return SIFT_HIP_ERR_LIMIT;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (!hip_ok(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)), "address of the matcher's static work area") || !p)
+            return SIFT_HIP_ERR_HIP;
+        g_scratch_ptr[dev] = (unsigned char*)p;
+    }
+    ctx->match_scratch = g_scratch_ptr[dev];
+    return SIFT_HIP_OK;
+}
+
+int run_match_noalloc(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
+                      int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
+    if (nq > kNoAllocMax || nr > kNoAllocMax) {
+        ctx->last_error = "sift_hip_match_u8_noalloc takes at most " + std::to_string(kNoAllocMax) +
+                          " queries and as many references";
+        return SIFT_HIP_ERR_LIMIT;
+    }
+    unsigned char* w = ctx->match_scratch;
+    if (!w) return SIFT_HIP_ERR_HIP;
+    const bool big = false;  // 256-query workgroups: at most 256 of them at the size limit
+    const int nq_pad = (nq + 255) / 256 * 256;
+    const int nr_pad = (nr + RT - 1) / RT * RT;
+    // Every row the kernels read (up to nq_pad / nr_pad) is rewritten by the two
+    // preparation launches, padding rows included, so nothing of an earlier call's
+    // contents is ever looked at and nothing has to be cleared.
+    launch_match(ctx->stream, big, d_q, nq, nq_pad, d_r, nr, nr_pad, (int8_t*)(w + kScrQ), (int*)(w + kScrQn),
+                 (int8_t*)(w + kScrR), (int*)(w + kScrRc), ratio, ratio_form, d_best, d_d1, d_d2);
     return SIFT_HIP_OK;
 }
 
