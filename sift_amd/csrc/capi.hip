@@ -300,7 +300,10 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     // With profiling on (or SIFT_HIP_SERIAL=1) everything runs on the main stream, so that
     // kernel durations are not inflated by another octave's kernels sharing the GPU.
     const bool serial = ctx->profiling || ctx->force_serial || noct < 2;
-    auto stream_of = [&](int oi) -> hipStream_t { return (serial || oi == 0) ? ctx->stream : ctx->side_stream; };
+    auto stream_of = [&](int oi) -> hipStream_t {
+        if (serial || oi == 0) return ctx->stream;
+        return (oi == 1 || ctx->n_side < 2) ? ctx->side_stream : ctx->side_stream2;
+    };
     if (frame_state == 1 && !serial) hipEventRecord(ctx->ev_start, ctx->stream);
     ctx->side_busy = !serial;
     // Host launch order: octave 0's pyramid first (long kernels that keep the main stream busy),
@@ -352,8 +355,16 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         if ((rc = enqueue_part(1, 0))) return rc;
         if ((rc = enqueue_part(1, 1))) return rc;
     }
+    // With a stream of their own the first of the small octaves goes in before the rest of octave
+    // 0, which the main stream does not reach before its pyramid kernels (about a millisecond at
+    // 4K) are done; the others follow it, so that the main stream never waits for the host.
+    const bool small_first = !serial && ctx->n_side >= 2 && noct > 2;
+    if (small_first) {
+        if ((rc = enqueue_part(2, 0))) return rc;
+        if ((rc = enqueue_part(2, 1))) return rc;
+    }
     if ((rc = enqueue_part(0, 1))) return rc;
-    for (int oi = 2; oi < noct; oi++) {
+    for (int oi = small_first ? 3 : 2; oi < noct; oi++) {
         if ((rc = enqueue_part(oi, 0))) return rc;
         if ((rc = enqueue_part(oi, 1))) return rc;
     }
@@ -369,7 +380,9 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
 static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow,
                           hipStream_t st = nullptr, bool join_side = true) {
     if (!st) st = ctx->stream;
-    if (join_side && ctx->side_busy && !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)"))
+    if (join_side && ctx->side_busy &&
+        (!hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)") ||
+         !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream2), "extract (second side stream)")))
         return SIFT_HIP_ERR_HIP;
     if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
                                     st), "read counters"))
@@ -495,13 +508,17 @@ static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Fetche
             return rc;
         }
         hipEventRecord(ctx->ev_frame[f & 1], ctx->stream);
-        if (ctx->side_busy) hipEventRecord(ctx->ev_side[f & 1], ctx->side_stream);
+        if (ctx->side_busy) {
+            hipEventRecord(ctx->ev_side[f & 1], ctx->side_stream);
+            hipEventRecord(ctx->ev_side2[f & 1], ctx->side_stream2);
+        }
         if (f >= 1) {
             swap_output_sets(ctx);  // look at frame f-1's set
             // The host waits for frame f-1 on both streams (frame f keeps the device busy
             // meanwhile), then copies on the copy stream: no stream ever waits for another.
             if (!hip_ok(ctx, hipEventSynchronize(ctx->ev_frame[(f - 1) & 1]), "batch frame") ||
-                (ctx->side_busy && !hip_ok(ctx, hipEventSynchronize(ctx->ev_side[(f - 1) & 1]), "batch frame (side)")))
+                (ctx->side_busy && (!hip_ok(ctx, hipEventSynchronize(ctx->ev_side[(f - 1) & 1]), "batch frame (side)") ||
+                                    !hip_ok(ctx, hipEventSynchronize(ctx->ev_side2[(f - 1) & 1]), "batch frame (side 2)"))))
                 return SIFT_HIP_ERR_HIP;
             int overflow = 0;
             rc = fetch_features(ctx, out + (size_t)(f - 1) * cap, cap, &n[f - 1], nullptr, &overflow, ctx->copy_stream,
@@ -555,6 +572,7 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     if (const char* e = std::getenv("SIFT_HIP_SERIAL")) ctx->force_serial = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_FULL_TOP")) ctx->full_top_level = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
+    if (const char* e = std::getenv("SIFT_HIP_NSIDE")) ctx->n_side = (e[0] == '1') ? 1 : 2;
     // the small octaves' stream gets the more urgent priority: their kernels are short and
     // latency-bound and would otherwise queue behind octave 0's large grids
     int prio_lo = 0, prio_hi = 0;
@@ -562,12 +580,16 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, ctx->side_priority == 0 ? 0 : prio_hi) !=
             hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, ctx->side_priority == 0 ? 0 : prio_hi) !=
+            hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_frame[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_frame[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_side[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_side[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_side2[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_side2[1], hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counters, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counters_alt, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         sift_hip_destroy(ctx);
@@ -586,6 +608,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
+    if (ctx->side_stream2) hipStreamSynchronize(ctx->side_stream2);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     for (OctWs& ws : ctx->lanes) {
         DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
@@ -608,10 +631,12 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     if (ctx->h_counters_alt) hipHostFree(ctx->h_counters_alt);
     for (hipEvent_t e : ctx->ev_frame) if (e) hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_side) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_side2) if (e) hipEventDestroy(e);
     for (auto& e : ctx->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->free_events) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+    if (ctx->side_stream2) hipStreamDestroy(ctx->side_stream2);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
     return SIFT_HIP_OK;
@@ -763,6 +788,7 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
         hipStreamSynchronize(ctx->copy_stream);
         hipStreamSynchronize(ctx->stream);
         hipStreamSynchronize(ctx->side_stream);
+        hipStreamSynchronize(ctx->side_stream2);
         if (!hip_ok(ctx, hipMemcpy(slot[0], frames + (size_t)f * px, px * 4, hipMemcpyHostToDevice), "upload frame"))
             return nullptr;
         return slot[0];
@@ -771,6 +797,7 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
     hipStreamSynchronize(ctx->copy_stream);
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->side_stream);
+    hipStreamSynchronize(ctx->side_stream2);
     for (int i = 0; i < 2; i++) hipEventDestroy(up[i]);
     return worst;
 }

@@ -82,7 +82,9 @@ struct Plan {
 struct sift_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side_stream = nullptr;  // octaves >= 1 of a frame (urgent priority); never waits on another stream
+    hipStream_t side_stream = nullptr;   // octave 1 of a frame (urgent priority); never waits on another stream
+    hipStream_t side_stream2 = nullptr;  // octaves >= 2: many short kernels that fill the gaps of the other two
+    int n_side = 2;                      // side streams in use (SIFT_HIP_NSIDE = 1: octaves >= 1 all on side_stream)
     hipStream_t copy_stream = nullptr;
     bool side_busy = false;             // the last enqueue put work on side_stream
     std::string last_error;
@@ -103,7 +105,8 @@ struct sift_hip_ctx {
     sifthip::RansacWs ransac;
     sifthip::DevBuf warp_src, warp_dst, warp_edges;
     hipEvent_t ev_frame[2] = {nullptr, nullptr};  // end of a batch frame's work on `stream` ...
-    hipEvent_t ev_side[2] = {nullptr, nullptr};   // ... and on `side_stream`
+    hipEvent_t ev_side[2] = {nullptr, nullptr};   // ... on `side_stream`
+    hipEvent_t ev_side2[2] = {nullptr, nullptr};  // ... and on `side_stream2`
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
 

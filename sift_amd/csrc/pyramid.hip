@@ -11,6 +11,9 @@
 // Each thread produces P consecutive outputs ALONG the filter direction and keeps
 // a sliding window of P inputs in registers, so a tap step costs one LDS read and
 // one scalar tap load for P multiply-accumulates.
+#include <algorithm>
+#include <cstdlib>
+
 #include "internal.h"
 
 namespace sifthip {
@@ -378,6 +381,150 @@ __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __res
 }
 
 
+// ---- exact column pass for short kernels: input-stationary ------------------------
+// The taps are symmetric bit for bit (g[k] == g[K-1-k]: the kernel is built from its
+// centre outwards), so the float product of an input with tap m serves two outputs,
+// and so does its conversion to double: (K+1)/2 multiplies and conversions per pixel
+// instead of K, the K additions staying.  Every output must still receive its
+// addends in ascending tap order, which for output row o is ascending input row
+// (addend k comes from row o + k - r).  A thread therefore walks down ONE column,
+// input row by input row, and keeps the K outputs that are in flight (rows iv-r ..
+// iv+r around input row iv) as double accumulators in registers: input iv adds
+// q[r-|d|] = (double)(float)(x * g[r-|d|]) to output iv+d for d = -r..r, which
+// completes output iv-r.  The accumulators form a ring (slot = row mod K); the loop
+// body covers K input rows, so every slot index in it is a compile-time constant.
+// No LDS: a wave reads 64 consecutive floats of each input row once (the next K
+// rows are fetched while the current K are consumed) and writes 64 floats per row.
+// A column is cut into segments of `seg` output rows, one wave each; a segment
+// first consumes the K-1 rows above it (its share of redundant work).
+
+// Buffer resource over `bytes` bytes at p (raw 32-bit elements, bounds-checked).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void blur_col_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int W, int H, const float* __restrict__ taps, int seg) {
+    constexpr int R = K / 2;
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x * 64 + lane;
+    const int xc = min(x, W - 1);  // lanes past the edge redo the last column and store nothing
+    const int y0 = blockIdx.y * seg;
+    const int y1 = min(y0 + seg, H);
+    float g[R + 1];
+#pragma unroll
+    for (int m = 0; m <= R; m++) g[m] = taps[m];
+    double acc[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) acc[j] = 0.0;
+    // Buffer addressing: one resource per wave over exactly the rows the segment may
+    // read (resp. write), a lane offset and a wave-uniform row offset per access, all
+    // below 2^31 whatever the image size.  Loads clamp the row offset to the resource
+    // (clamp to edge); stores are never branched around: a row outside the segment or
+    // a lane past the right edge yields an offset outside the resource, which the
+    // hardware drops.
+    const int yb = max(0, y0 - R);                   // first row the segment reads
+    const int rows_in = min(H, y1 + R) - yb;         // rows it may read
+    const __amdgpu_buffer_rsrc_t rin = buffer_of(in + (size_t)yb * W, (unsigned)((size_t)rows_in * W * 4));
+    const __amdgpu_buffer_rsrc_t rout = buffer_of(out + (size_t)y0 * W, (unsigned)((size_t)(y1 - y0) * W * 4));
+    const int row_bytes = W * 4;
+    const int voff = xc * 4;
+    const int last_in = (rows_in - 1) * row_bytes;
+    // rows above the image clamp to row 0, rows below it to row H-1: both are ends of the resource
+    // whenever the clamp can apply (yb == 0 resp. yb + rows_in == H)
+    int in_off = (y0 - R - yb) * row_bytes;  // offset of the next input row to fetch
+    auto load_next = [&]() -> float {
+        const int off = max(0, min(in_off, last_in));
+        in_off += row_bytes;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff, off, 0));
+    };
+    // byte offset of the output the next step completes, per lane; starts 2R rows above the segment
+    // (negative = far beyond the resource as an unsigned offset) and advances one row per step
+    unsigned st_off = (x < W ? (unsigned)voff : 0x80000000u) + (unsigned)(-2 * R * row_bytes);
+    float cur[K], nxt[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) cur[t] = load_next();
+    // The float products of a step are formed one step ahead (a conversion issued right
+    // behind the multiply that feeds it would stall the wave for the multiply's latency,
+    // and so would an addition right behind its conversion); each step runs
+    // conversions -> next step's products -> additions, in that order.
+    constexpr int NP = (R + 2) / 2;  // packed multiplies per input
+    float_pair pr[NP];
+    auto products = [&](float xv) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const float_pair gp = {g[2 * i], (2 * i + 1 <= R) ? g[2 * i + 1] : 0.f};
+            pr[i] = gp * xv;  // one packed multiply, each half rounded to float as xv * g[m] is
+        }
+    };
+    products(cur[0]);
+    for (int iv0 = y0 - R; iv0 - R < y1; iv0 += K) {  // body: input rows iv0 .. iv0+K-1; slot of output row o is (o - (y0 - R)) mod K
+#pragma unroll
+        for (int t = 0; t < K; t++) nxt[t] = load_next();
+#pragma unroll
+        for (int t = 0; t < K; t++) {
+            double q[R + 1];
+#pragma unroll
+            for (int m = 0; m <= R; m++) q[m] = (double)((m & 1) ? pr[m >> 1].y : pr[m >> 1].x);
+            __builtin_amdgcn_sched_barrier(0);
+            products(t + 1 < K ? cur[t + 1] : nxt[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = -R; d <= R; d++) acc[(t + d + K) % K] += q[R - (d < 0 ? -d : d)];
+            constexpr int kSlotBase = K - R;
+            const int slot = (t + kSlotBase) % K;  // output row iv0 + t - R is complete
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[slot]), rout, (int)st_off, 0, 0);
+            st_off += (unsigned)row_bytes;
+            acc[slot] = 0.0;
+            // Pin every accumulator here: left alone the compiler moves additions and
+            // conversions across steps and keeps hundreds of converted products alive.
+#pragma unroll
+            for (int j = 0; j < K; j++) asm volatile("" : "+v"(acc[j]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < K; t++) cur[t] = nxt[t];
+    }
+}
+
+// Segment length of the streaming column pass: one round of waves (as many as the
+// kernel's register count lets a SIMD hold), so that none waits for a free slot while
+// others finish, and segments long enough to keep the K-1 rows of lead-in cheap.
+static int stream_segment(int W, int H, int K) {
+    if (const char* e = std::getenv("SIFT_BLUR_SEG")) return std::max(1, std::atoi(e));
+    const int cols = (W + 63) / 64;
+    const int waves_per_simd = K <= 11 ? 6 : K <= 21 ? 4 : 2;
+    const int nseg = std::max(1, 1024 * waves_per_simd / cols);
+    return std::min(H, std::max((H + nseg - 1) / nseg, 2 * K));
+}
+
+template <int K>
+static void launch_col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps) {
+    const int seg = stream_segment(W, H, K);
+    dim3 grid((W + 63) / 64, (H + seg - 1) / seg);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_stream_kernel<K>), grid, dim3(64), 0, st, tmp, dst, W, H, d_taps, seg);
+}
+
+// true if a streaming kernel exists for this tap count (the pyramid's own short kernels)
+static bool col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps, int K) {
+    if (const char* e = std::getenv("SIFT_BLUR_STREAM")) {
+        if (e[0] == '0') return false;
+    } else if ((size_t)W * H < ((size_t)16 << 20)) {
+        // smaller images give too few waves once the segments are long enough to pay for their
+        // lead-in (measured on 3840x2160: slower than the tiled pass at every segment length)
+        return false;
+    }
+    switch (K) {
+        case 11: launch_col_stream<11>(st, tmp, dst, W, H, d_taps); return true;
+        case 15: launch_col_stream<15>(st, tmp, dst, W, H, d_taps); return true;
+        case 21: launch_col_stream<21>(st, tmp, dst, W, H, d_taps); return true;
+        case 29: launch_col_stream<29>(st, tmp, dst, W, H, d_taps); return true;
+        case 39: launch_col_stream<39>(st, tmp, dst, W, H, d_taps); return true;
+        default: return false;
+    }
+}
+
 template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                            const float* d_taps, int K) {
@@ -395,6 +542,9 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
     }
     {
         ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
+        if constexpr (sizeof(ACC) == sizeof(double)) {
+            if (col_stream(st, tmp, dst, W, H, d_taps, K)) return;
+        }
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
         int TH = 16 * P;
         while (TH > 4 * P && (size_t)(TH + K - 1 + P) * 256 > 32 * 1024) TH >>= 1;

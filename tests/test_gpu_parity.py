@@ -433,6 +433,34 @@ def test_blur_and_resample_random_shapes(sift, oracle):
                 assert np.array_equal(bits(sift.first(img, ratio)), bits(oracle.first(img, ratio))), (case, w, h, ratio)
 
 
+def test_streaming_column_pass_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
+    """The input-stationary column pass (used by itself only on images of 16 Mpixel and more)
+    forced onto small and ragged images, with segment lengths that cut columns at awkward rows:
+    every tap count it is instantiated for, widths that are not multiples of 64, images shorter
+    than the kernel, one-row and one-column images."""
+    monkeypatch.setenv("SIFT_BLUR_STREAM", "1")
+    rng = np.random.default_rng(31)
+    shapes = [(200, 131), (64, 300), (1, 77), (130, 1), (65, 40), (333, 95)]
+    for p, K in ((1.6, 11), (2.2627418, 15), (3.2, 21), (4.5254836, 29), (6.4, 39)):
+        assert len(oracle.gau_matrix(p)) == K
+        for i, (w, h) in enumerate(shapes):
+            img = rng.random((h, w), dtype=np.float32)
+            if i % 2:
+                img[rng.random((h, w)) < 0.3] = 0.0  # exact zeros: +0.0 sums must stay +0.0
+            want = bits(oracle.gau_blur(img, p))
+            for seg in (None, 1, 7, 37, 1000):
+                if seg is None:
+                    monkeypatch.delenv("SIFT_BLUR_SEG", raising=False)
+                else:
+                    monkeypatch.setenv("SIFT_BLUR_SEG", str(seg))
+                assert np.array_equal(bits(sift.gau_blur(img, p)), want), (K, w, h, seg)
+    monkeypatch.delenv("SIFT_BLUR_SEG", raising=False)
+    # negative inputs and negative zeros (the public Gaus::GauBlur takes any float image)
+    img = (rng.random((90, 150), dtype=np.float32) - 0.5).astype(np.float32)
+    img[::7] = -0.0
+    assert np.array_equal(bits(sift.gau_blur(img, 3.2)), bits(oracle.gau_blur(img, 3.2)))
+
+
 def test_two_contexts_extract_concurrently(sift):
     """Two contexts on one device driven from two threads: each keeps its two streams (the
     library joins them on the host, no stream waits on another's event) and both give the
