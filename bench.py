@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--match-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pageable-out", action="store_true", help="feature array in ordinary host memory (A/B)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the 1080p batch / 8192^2 / reference-octave-count legs")
+    ap.add_argument("--no-large", action="store_true", help="skip the 8192^2 frame")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo + SIFT_BENCH_ONE_GPU=1: rehearsal of the multi-rank path on one GPU (collectives on the CPU)")
     args = ap.parse_args()
@@ -135,6 +137,9 @@ def main():
         stage_bytes_per_px = levels * 8 + (levels - 1) * 4
         big = [p for p in px if p >= (3 << 20)]          # octaves handled by the 8-outputs-per-thread kernels
         dom = max(("blur_col", "blur_row"), key=lambda k: prof[k][0])
+        kname = {"blur_col": "column pass of the octaves of 3 Mpixel and more (blur_col_stream_kernel<K> at octave 0, "
+                             "blur_col_kernel<double, 8> at octave 1)",
+                 "blur_row": "blur_row_kernel<double, 8>"}[dom] if args.blur_mode == 0 else None
         n_dom = prof[dom][1] // nprof
         avg_ms = prof[dom][0] / max(prof[dom][1], 1)
         alg_launch = 8.0 * sum(big) / max(len(big), 1)   # the class's launches differ only in tap count
@@ -142,20 +147,29 @@ def main():
         blur_keys = ("blur_row", "blur_col", "blur_row_small", "blur_col_small")
         t_stage = sum(prof[k][0] for k in blur_keys) / nprof
         alg_stage = sum(px) * stage_bytes_per_px
+        # Measured HBM traffic of the class's kernels comes from the rocprofv3 PMC passes kept under
+        # profiles/ (they cannot run inside this process); it is reported only while that summary was
+        # taken from the kernel sources this run uses (hash of pyramid.hip), never from an older build.
         traffic = None
         traffic_note = None
         import glob
+        import hashlib
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))  # newest round/letter last
         tpath = tfiles[-1] if tfiles else ""
-        kname = {"blur_col": "blur_col_kernel<double, 8>", "blur_row": "blur_row_kernel<double, 8>"}[dom] \
-            if args.blur_mode == 0 else None
-        if kname and os.path.exists(tpath) and (W, H, args.octaves) == (3840, 2160, 4):
+        src_hash = hashlib.sha256(open(os.path.join(ROOT, "sift_amd", "csrc", "pyramid.hip"), "rb").read()).hexdigest()
+        if os.path.exists(tpath) and (W, H, args.octaves, args.blur_mode) == (3840, 2160, 4, 0):
             tj = json.load(open(tpath))
-            kk = tj["kernels"].get(kname)
-            if kk:
-                traffic = round((kk["read"] + kk["write"]) / kk["launches_per_frame"])
-                traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this workload, " \
-                               "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, per launch; profiles/" + os.path.basename(tpath)
+            if tj.get("kernel_source_sha256") == src_hash:
+                want = ("blur_col_kernel<double, 8>", "blur_col_stream_kernel") if dom == "blur_col" else ("blur_row_kernel<double, 8>",)
+                kk = [v for k, v in tj["kernels"].items() if k.startswith(want)]
+                nl = sum(v["launches_per_frame"] for v in kk)
+                if kk and nl:
+                    traffic = round(sum(v["read"] + v["write"] for v in kk) / nl)
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this workload and these " \
+                                   "kernel sources, 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, per launch; profiles/" + \
+                                   os.path.basename(tpath)
+            else:
+                traffic_note = "profiles/%s was measured on other kernel sources: not reported" % os.path.basename(tpath)
         # VALU floor of the exact blur: 4.56 ns per wave-level (half a v_pk_mul_f32, v_cvt_f64_f32, v_add_f64)
         # triple per SIMD (tools/microbench_valu.hip), 1024 SIMDs
         # levels built as images: the library evaluates the last level only around top-layer
@@ -197,6 +211,40 @@ def main():
                     "HBM-bound; frac_of_valu_floor is the efficiency against that bound for the levels that are "
                     "built as images (the last level of each octave is evaluated only at the 3x3 neighbourhoods "
                     "of top-layer extrema, inside the detect class)",
+        }
+
+    # ---- the same stage with the fp32-FMA blur (blur_mode 1): no fp64 floor, so this is where the
+    # HBM roofline applies to the pyramid; not the reference's arithmetic, never `value` -------------
+    roofline_fast = None
+    if rank == 0 and args.blur_mode == 0:
+        fast = SiftParams(octaves=args.octaves, blur_mode=1)
+        ctx.extract_dev(d_frame, W, H, fast, out)
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        for _ in range(3):
+            ctx.extract_dev(d_frame, W, H, fast, out)
+        pf = ctx.profile_read(reset=True)
+        ctx.profile(False)
+        ctx.extract_dev(d_frame, W, H, prm, out)  # back to the exact plan
+        t_fast = sum(pf[k][0] for k in ("blur_row", "blur_col", "blur_row_small", "blur_col_small")) / 3
+        launches = sum(pf[k][1] for k in ("blur_row", "blur_col", "blur_row_small", "blur_col_small")) // 3
+        px = pyramid_pixels(W, H, args.octaves)
+        levels = prm.intvls + 3
+        alg = sum(px) * (levels * 8 + (levels - 1) * 4)
+        domf = max(("blur_col", "blur_row"), key=lambda k: pf[k][0])
+        bigpx = [p_ for p_ in px if p_ >= (3 << 20)]
+        alg_l = 8.0 * sum(bigpx) / max(len(bigpx), 1)
+        avg = pf[domf][0] / max(pf[domf][1], 1)
+        roofline_fast = {
+            "blur_mode": 1, "bound": "hbm", "kernel": domf + " class (dominant by total time)",
+            "achieved": round(alg_l / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg_l / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": round(alg_l), "avg_launch_ms": round(avg, 5),
+            "pyramid_stage": {"launches_per_frame": launches, "algorithmic_bytes_per_frame": alg,
+                              "ms_per_frame": round(t_fast, 4),
+                              "achieved_GBps": round(alg / (t_fast * 1e-3) / 1e9, 1),
+                              "frac": round(alg / (t_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "stage_ms_per_frame": {k: round(v[0] / 3, 4) for k, v in pf.items() if v[1]},
         }
 
     # ---- side measurements (rank 0, outside the timed region; none of them is `value`) -------
@@ -290,6 +338,66 @@ def main():
         extras["warp_cylinder_kernel_ms"] = round(ctx.profile_read()["warp"][0], 4)
         ctx.profile(False)
 
+    # ---- the other single-GPU configurations of the baseline (rank 0, N = 1; not `value`) ----------
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        import ctypes as C
+        configs = {}
+        # the reference's own octave count for this frame (getPyramidOctv: 7 at 3840x2160) next to the
+        # 4-octave workload that `value` is quoted on
+        auto = SiftParams(octaves=0, blur_mode=args.blur_mode)
+        na = ctx.extract_dev(d_frame, W, H, auto, out)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            na = ctx.extract_dev(d_frame, W, H, auto, out)
+        configs["frame_reference_octave_count"] = {
+            "workload": "%dx%d frame, octaves = %d (the reference's own count)" % (W, H, sift_amd.pyramid_octaves(W, H)),
+            "ms_per_frame": round((time.perf_counter() - t0) / 5 * 1e3, 3), "features": int(na)}
+        ctx.extract_dev(d_frame, W, H, prm, out)
+        # 1080p batch: 64 frames resident in HBM through the pipelined batch entry point
+        bw, bh, nb = 1920, 1080, 64
+        f1080 = sift_amd.blob_image(bw, bh, seed=1)
+        d_b = torch.from_numpy(f1080).to(dev).reshape(1, -1).repeat(nb, 1).contiguous()
+        bcap = 1 << 14
+        bout = ctx.pinned_array(nb * bcap, sift_amd.FEAT_DTYPE).reshape(nb, bcap)
+        bn = np.zeros(nb, np.int32)
+        p4 = SiftParams(octaves=4, blur_mode=args.blur_mode)
+        for _ in range(2):
+            ctx.extract_batch_dev(d_b, bw, bh, nb, p4, bout, bn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.extract_batch_dev(d_b, bw, bh, nb, p4, bout, bn)
+        bt = time.perf_counter() - t0
+        configs["batch_1080p"] = {"workload": "%d frames 1920x1080, 4 octaves, resident in HBM, sift_hip_extract_batch_dev" % nb,
+                                  "frames_per_s": round(nb / bt, 1), "ms_per_frame": round(bt / nb * 1e3, 4),
+                                  "features_per_frame": int(bn[0])}
+        del d_b
+        # one 8192 x 8192 frame, 6 octaves
+        if not args.no_large:
+            torch.cuda.empty_cache()
+            lw = lh = 8192
+            big = sift_amd.blob_image(lw, lh, seed=5)
+            d_big = torch.from_numpy(big).to(dev)
+            lout = ctx.pinned_array(1 << 19, sift_amd.FEAT_DTYPE)
+            p6 = SiftParams(octaves=6, blur_mode=args.blur_mode)
+            free0, total_mem = torch.cuda.mem_get_info()
+            nl = ctx.extract_dev(d_big, lw, lh, p6, lout)
+            nl = ctx.extract_dev(d_big, lw, lh, p6, lout)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                nl = ctx.extract_dev(d_big, lw, lh, p6, lout)
+            lt = (time.perf_counter() - t0) / 3
+            free1, _ = torch.cuda.mem_get_info()
+            lpx = pyramid_pixels(lw, lh, 6)
+            lalg = sum(lpx) * ((prm.intvls + 3) * 8 + (prm.intvls + 2) * 4)
+            configs["frame_8192"] = {"workload": "one 8192x8192 frame, 6 octaves, resident in HBM", "ms_per_frame": round(lt * 1e3, 2),
+                                     "features": int(nl),
+                                     "device_memory_in_use_GiB": round((total_mem - free1) / 2 ** 30, 2),
+                                     "pyramid_algorithmic_GBps_over_whole_frame_time": round(lalg / lt / 1e9, 1)}
+            del d_big
+
     # ---- match leg ---------------------------------------------------------------------
     match = None
     if args.match_n > 0:
@@ -360,6 +468,19 @@ def main():
             "sample": "oracle/sift_oracle.cpp on a %dx%d crop of the same frame, %d octaves: %.2f s, %d features; "
                       "scaled by pixel count to a full %dx%d frame" % (cw, ch, args.octaves, ct, len(fo), W, H),
         }
+        # every host core of this process's share, one oracle call per thread over independent 1080p
+        # frames (the oracle is plain C behind ctypes, which drops the interpreter lock during the call)
+        import concurrent.futures as cf
+        ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+        frames1080 = [sift_amd.blob_image(1920, 1080, seed=100 + i) for i in range(ncores)]
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(ncores) as ex:
+            counts = list(ex.map(lambda f: len(orc.extract(f, octaves=4)[0]), frames1080))
+        at = time.perf_counter() - t0
+        cpu["all_cores"] = {"cores": ncores, "nproc": os.cpu_count(), "frames_per_s_1080p": round(ncores / at, 4),
+                            "frames_per_s_4k_equivalent": round(ncores / at * (1920 * 1080) / float(W * H), 5),
+                            "sample": "%d threads x one 1920x1080 frame each (4 octaves): %.2f s wall, %d features in all"
+                                      % (ncores, at, sum(counts))}
         if args.match_n > 0:
             qs, rs = sift_amd.planted_descriptors(4096, 32768)
             t0 = time.perf_counter()
@@ -367,6 +488,12 @@ def main():
             mt = time.perf_counter() - t0
             cpu["match_gpairs_per_s"] = round(4096 * 32768 / mt / 1e9, 5)
             cpu["match_sample"] = "oracle exact NN, 4096 x 32768 descriptors, 1 thread, %.2f s" % mt
+            qs2 = [sift_amd.planted_descriptors(1024, 32768, seed_q=20 + i, seed_r=3)[0] for i in range(ncores)]
+            t0 = time.perf_counter()
+            with cf.ThreadPoolExecutor(ncores) as ex:
+                list(ex.map(lambda q_: orc.match_u8(q_, rs, 0.5, 0), qs2))
+            mt2 = time.perf_counter() - t0
+            cpu["all_cores"]["match_gpairs_per_s"] = round(ncores * 1024 * 32768 / mt2 / 1e9, 5)
 
     if rank == 0:
         line = {
@@ -387,7 +514,9 @@ def main():
                                                                                                prm.intvls + 2),
                        "features_per_frame": int(nfeat), "blur_mode": args.blur_mode, "parallelism": "dp%d" % world},
             "roofline": roofline,
+            "roofline_blur_mode_1": roofline_fast,
             "cpu_baseline": cpu,
+            "configs": configs,
             "match": match,
             "extras": extras,
         }

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence kept under profiles/: per-kernel statistics of a serialised 4K
+# extract (one stream, so durations are not inflated by overlap), of a 1080p extract and of the
+# 8192^2 frame, and the FETCH_SIZE / WRITE_SIZE passes (separate runs) that give the HBM traffic per
+# kernel.  Run on the GPU box from the repository root:  bash tools/collect_profiles.sh <tag>
+# Results land in gpurun_out/prof_<tag>/; copy the summaries to profiles/.
+set -e
+tag=${1:-r02}
+root=$PWD
+out=$root/gpurun_out/prof_$tag
+rm -rf $out && mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $root
+export SIFT_HIP_SERIAL=1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4k -- python3 tools/profile_extract.py --steps 5 > $out/stats4k.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1080 -- python3 tools/profile_extract.py --steps 5 --width 1920 --height 1080 > $out/stats1080.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats8k -- python3 tools/profile_extract.py --steps 3 --width 8192 --height 8192 --octaves 6 > $out/stats8k.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4k_fast -- python3 tools/profile_extract.py --steps 5 --blur-mode 1 > $out/stats4k_fast.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 tools/profile_extract.py --steps 2 > $out/pmc_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 tools/profile_extract.py --steps 2 > $out/pmc_write.log 2>&1
+python3 tools/summarize_pmc.py $out/pmc_fetch $out/pmc_write 2 > $out/traffic.json
+for d in stats4k stats1080 stats8k stats4k_fast; do cp $out/$d/*/*kernel_stats.csv $out/${d}_kernel_stats.csv; done
+rm -rf $out/stats4k $out/stats1080 $out/stats8k $out/stats4k_fast $out/pmc_fetch $out/pmc_write
+ls -la $out
