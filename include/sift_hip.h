@@ -178,6 +178,20 @@ int sift_hip_match_u8_sharded(sift_hip_ctx* ctx, void* comm, int nranks, const u
                               const uint8_t* d_r_local, int nr_local, float ratio, int ratio_form, int32_t* d_best,
                               int32_t* d_d1, int32_t* d_d2);
 
+/* The same when the ranks hold different numbers of references (real frames give unequal
+ * feature counts).  nr_of_rank: host array of nranks counts, identical on every rank (e.g. the
+ * gathered per-frame feature counts); this rank contributes nr_of_rank[rank] rows of d_r_local.
+ * The shards are padded to the largest count for one ncclAllGather and compacted on the device,
+ * so best indexes the rank-ordered concatenation WITHOUT padding: rank k's reference i is
+ * (sum of nr_of_rank[0..k)) + i, as sift_hip_ragged_offsets computes.  No host synchronisation. */
+int sift_hip_match_u8_sharded_ragged(sift_hip_ctx* ctx, void* comm, int nranks, int rank, const uint8_t* d_q, int nq,
+                                     const uint8_t* d_r_local, const int32_t* nr_of_rank, float ratio, int ratio_form,
+                                     int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
+/* Index arithmetic of the call above (host only, no GPU work): offsets[k] = first index of rank
+ * k's references in the concatenation, offsets[nranks] = their total; returns the largest count,
+ * or a negative status (a negative count, or a total beyond INT32_MAX). */
+int sift_hip_ragged_offsets(const int32_t* nr_of_rank, int nranks, int64_t* offsets);
+
 /* ---- RANSAC homography over the matches: replaces ransac_xform, ---------------------
  * Sift/ransac/xform.cpp:37-168 (its call site: Stitching::Check, Sift.cpp:684) --------
  * q_feats[0..nq): image-2 features (the matcher's queries), r_feats[0..nr): image-1

@@ -114,6 +114,9 @@ def load_library() -> C.CDLL:
         "sift_hip_match_u8_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_match_u8_noalloc": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_match_u8_sharded": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+        "sift_hip_match_u8_sharded_ragged": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_float, C.c_int, vp,
+                                                       vp, vp]),
+        "sift_hip_ragged_offsets": (C.c_int, [vp, C.c_int, vp]),
         "sift_hip_ransac_homog": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_uint,
                                             vp, vp, ip, ip]),
         "sift_hip_ransac_homog_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float,

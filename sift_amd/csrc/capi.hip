@@ -617,7 +617,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
             if (b->p) hipFree(b->p);
     }
     DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->table, &ctx->layer_consts,
-                      &ctx->gcounters, &ctx->gcounters_alt, &ctx->gathered, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
+                      &ctx->gcounters, &ctx->gcounters_alt, &ctx->gathered, &ctx->gather_in, &ctx->gather_pad, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all,
                       &ctx->ransac.blk, &ctx->ransac.pairs, &ctx->ransac.src, &ctx->ransac.flags, &ctx->ransac.samples,
                       &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best,
@@ -944,6 +944,70 @@ int sift_hip_match_u8_sharded(sift_hip_ctx* ctx, void* comm, int nranks, const u
         if (nrc != 0) {
             ctx->last_error = "ncclAllGather failed with code " + std::to_string(nrc);
             return SIFT_HIP_ERR_HIP;
+        }
+    }
+    if (nq == 0) return SIFT_HIP_OK;
+    rc = run_match(ctx, d_q, nq, (const uint8_t*)ctx->gathered.p, nr_all, ratio, ratio_form, d_best, d_d1, d_d2);
+    if (rc) return rc;
+    return check_async(ctx, "sharded match launch");
+}
+
+int sift_hip_ragged_offsets(const int32_t* nr_of_rank, int nranks, int64_t* offsets) {
+    if (!nr_of_rank || !offsets || nranks < 1) return SIFT_HIP_ERR_ARG;
+    int64_t run = 0;
+    int32_t largest = 0;
+    for (int k = 0; k < nranks; k++) {
+        if (nr_of_rank[k] < 0) return SIFT_HIP_ERR_ARG;
+        offsets[k] = run;
+        run += nr_of_rank[k];
+        largest = std::max(largest, nr_of_rank[k]);
+    }
+    offsets[nranks] = run;
+    if (run > INT32_MAX) return SIFT_HIP_ERR_LIMIT;
+    return largest;
+}
+
+int sift_hip_match_u8_sharded_ragged(sift_hip_ctx* ctx, void* comm, int nranks, int rank, const uint8_t* d_q, int nq,
+                                     const uint8_t* d_r_local, const int32_t* nr_of_rank, float ratio, int ratio_form,
+                                     int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
+    if (bad_ctx(ctx) || !comm || nranks < 1 || rank < 0 || rank >= nranks || !nr_of_rank || nq < 0 ||
+        (nq > 0 && (!d_q || !d_best)))
+        return SIFT_HIP_ERR_ARG;
+    if (ratio_form != 0 && ratio_form != 1) return SIFT_HIP_ERR_ARG;
+    std::vector<int64_t> off((size_t)nranks + 1);
+    const int largest = sift_hip_ragged_offsets(nr_of_rank, nranks, off.data());
+    if (largest < 0) return largest;
+    const int nr_local = nr_of_rank[rank];
+    if (nr_local > 0 && !d_r_local) return SIFT_HIP_ERR_ARG;
+    const int nr_all = (int)off[nranks];
+    int rc;
+    if ((rc = ensure(ctx, ctx->gathered, std::max<size_t>(1, (size_t)nr_all * 128)))) return rc;
+    if (largest > 0) {
+        // every rank sends `largest` rows (its own, then padding whose content nobody reads) ...
+        const size_t slot = (size_t)largest * 128;
+        if ((rc = ensure(ctx, ctx->gather_in, slot))) return rc;
+        if ((rc = ensure(ctx, ctx->gather_pad, slot * nranks))) return rc;
+        allgather_fn ag = find_allgather();
+        if (!ag) {
+            ctx->last_error = "ncclAllGather not found in this process (load RCCL before calling)";
+            return SIFT_HIP_ERR_HIP;
+        }
+        if (nr_local > 0 &&
+            !hip_ok(ctx, hipMemcpyAsync(ctx->gather_in.p, d_r_local, (size_t)nr_local * 128, hipMemcpyDeviceToDevice,
+                                        ctx->stream), "stage references"))
+            return SIFT_HIP_ERR_HIP;
+        const int nrc = ag(ctx->gather_in.p, ctx->gather_pad.p, slot, /*ncclUint8*/ 1, comm, ctx->stream);
+        if (nrc != 0) {
+            ctx->last_error = "ncclAllGather failed with code " + std::to_string(nrc);
+            return SIFT_HIP_ERR_HIP;
+        }
+        // ... and the padding is squeezed out: rank k's rows move to offset off[k]
+        for (int k = 0; k < nranks; k++) {
+            if (nr_of_rank[k] == 0) continue;
+            if (!hip_ok(ctx, hipMemcpyAsync((uint8_t*)ctx->gathered.p + (size_t)off[k] * 128,
+                                            (const uint8_t*)ctx->gather_pad.p + slot * k, (size_t)nr_of_rank[k] * 128,
+                                            hipMemcpyDeviceToDevice, ctx->stream), "compact references"))
+                return SIFT_HIP_ERR_HIP;
         }
     }
     if (nq == 0) return SIFT_HIP_OK;

@@ -140,9 +140,49 @@ SIFT_HD inline float homog_xfer_err(const float* T, float x, float y, float u, f
 // Smallest consensus size for which the chance that a wrong model gathers it is
 // below p_badxform (xform.cpp:246-281).  The reference's helper sums log(i) over
 // [n-m, n] and over [n-i, n], one term more than a binomial coefficient needs, so
-// the factorials here are of n-m-1 and n-i-1, and its i = n term takes log(0) and
-// comes out as exp(-inf) = 0.  Evaluated in double through lgamma.
+// the factorials are of n-m-1 and n-i-1, and its i = n term takes log(0) and
+// comes out as exp(-inf) = 0.
+// Up to kMinInliersFloatN matches the sums are accumulated exactly as the reference
+// accumulates them: float additions of logf(i) in ascending i, each range summed
+// from zero (about n^2/2 additions, which is why there is a limit), every operation
+// of the expression in float and in its order.  Beyond the limit the same
+// quantities are evaluated in double through lgamma; the result can then differ
+// from the reference's by one at most (tested against the float form).
+constexpr int kMinInliersFloatN = 8192;
+
+inline int ransac_min_inliers_float(int n, int m, float p_badsupp, float p_badxform) {
+    SIFT_NO_CONTRACT
+    std::vector<float> lg((size_t)n + 1), fact((size_t)n + 1, 0.f), term((size_t)n + 1, 0.f);
+    for (int i = 0; i <= n; i++) lg[(size_t)i] = logf((float)i);  // lg[0] = -inf, used by the i = n term only
+    for (int i = 1; i <= n; i++) fact[(size_t)i] = fact[(size_t)i - 1] + lg[(size_t)i];  // log_factorial(i)
+    auto log_range = [&](int a, int b) {  // _log_factorial(a, b)
+        float f = 0.f;
+        for (int i = a; i <= b; i++) f += lg[(size_t)i];
+        return f;
+    };
+    const float log_n = fact[(size_t)n];
+    const float log_nm = log_n - log_range(n - m, n);
+    const float lb = logf(p_badsupp), lgood = logf(1.f - p_badsupp);
+    float total = 0.f;
+    for (int i = m + 1; i <= n; i++) {
+        float pi = (float)(i - m) * lb + (float)(n - i + m) * lgood;
+        pi = pi + log_nm;
+        pi = pi - fact[(size_t)(i - m)];
+        pi = pi - (log_n - log_range(n - i, n));
+        term[(size_t)i] = expf(pi);
+        total += term[(size_t)i];
+    }
+    float sum = total;
+    int j = m + 1;
+    for (; j <= n; j++) {
+        sum -= term[(size_t)j];
+        if (sum < p_badxform) break;
+    }
+    return j;
+}
+
 inline int ransac_min_inliers(int n, int m, float p_badsupp, float p_badxform) {
+    if (n <= kMinInliersFloatN) return ransac_min_inliers_float(n, m, p_badsupp, p_badxform);
     const double lb = log((double)p_badsupp), lg = log(1.0 - (double)p_badsupp);
     const double log_nm = lgamma((double)(n - m));  // log((n-m-1)!)
     std::vector<double> term((size_t)(n > 0 ? n : 0) + 1, 0.0);

@@ -101,6 +101,7 @@ struct sift_hip_ctx {
     int32_t* h_counters_alt = nullptr;  // ... and the other set's
     sifthip::DevBuf gcounters_alt;
     sifthip::DevBuf gathered;  // all ranks' reference descriptors (sharded match)
+    sifthip::DevBuf gather_in, gather_pad;  // ragged shards: this rank's padded contribution, all ranks' padded shards
     unsigned char* match_scratch = nullptr;  // this device's copy of the matcher's static work area (not owned)
     sifthip::RansacWs ransac;
     sifthip::DevBuf warp_src, warp_dst, warp_edges;

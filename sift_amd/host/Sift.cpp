@@ -32,6 +32,23 @@ sift_hip_ctx* default_context() {
     return ctx;
 }
 
+static std::recursive_mutex& context_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
+ContextUse::ContextUse() : ctx(nullptr) {
+    context_mutex().lock();
+    try {
+        ctx = default_context();
+    } catch (...) {
+        context_mutex().unlock();
+        throw;
+    }
+}
+
+ContextUse::~ContextUse() { context_mutex().unlock(); }
+
 Options& options() {
     static Options o;
     return o;
@@ -48,7 +65,8 @@ void Gaus::GauBlur(std::vector<float>& img_gau, const std::vector<float>& img_or
     if (&img_gau == &img_ori) throw file_same("## Erroe! in and out is same.");  // imglib.cpp:76-78
     if (img_ori.size() < width * height) throw Size_error("GauBlur: image smaller than width*height");
     img_gau.resize(height * width);
-    sift_hip_ctx* ctx = default_context();
+    sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
     check(ctx, sift_hip_gau_blur(ctx, img_ori.data(), img_gau.data(), (int)width, (int)height, p, (int)mat_len,
                                  sift_amd::options().blur_mode), "sift_hip_gau_blur");
 }
@@ -70,7 +88,8 @@ void Scaling::first(std::vector<float>& img, std::vector<float>& img_ori, size_t
     const int newW = static_cast<int>(std::floor(width * Ratio));
     if (newH < 1 || newW < 1) throw Size_error("Scaling::first: empty result");
     img.resize((size_t)newH * newW);
-    sift_hip_ctx* ctx = default_context();
+    sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
     check(ctx, sift_hip_first(ctx, img_ori.data(), (int)width, (int)height, Ratio, img.data()), "sift_hip_first");
 }
 
@@ -116,7 +135,8 @@ const float ImgRaw::atBilinear(float y, float x) const {
 ImgRaw ImgRaw::ConverGray() const {
     if (bitCount == 24) {
         ImgRaw gray(width, height, 8);
-        sift_hip_ctx* ctx = default_context();
+        sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
         check(ctx, sift_hip_convert_gray(ctx, raw_img.data(), (int)(width * height), gray.raw_img.data()),
               "sift_hip_convert_gray");
         return gray;
@@ -151,14 +171,16 @@ void Sift::pyramid() {
     if (raw_img.bitCount != 8 && raw_img.bitCount != 24) throw Size_error("Sift::pyramid: bitCount must be 8 or 24");
     if (raw_img.raw_img.size() < (size_t)raw_img.width * raw_img.height * (raw_img.bitCount / 8))
         throw Size_error("Sift::pyramid: image buffer smaller than width*height");
-    sift_hip_ctx* ctx = default_context();
+    sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
     sift_hip_params prm;
     sift_hip_default_params(&prm);
     prm.intvls = (int)pyWidth - SIFT_INTVLS_DIFF;
     prm.octaves = sift_amd::options().octaves;
     prm.subpixel = sift_amd::options().subpixel;
     prm.blur_mode = sift_amd::options().blur_mode;
-    // The records come back into a page-locked buffer kept for the process (direct DMA).
+    // The records come back into a page-locked buffer kept beside the shared context (direct
+    // DMA); like the context it is only touched while `use` holds the context lock.
     static sift_hip_feat* buf = nullptr;
     static int buf_cap = 0;
     int cap = buf_cap > 0 ? buf_cap : 1 << 15, n = 0;
@@ -243,7 +265,8 @@ size_t Stitching::Match(float matchTh) {
     pack(feat2, feat2_Count, q);
     pack(feat1, feat1_Count, r);
     std::vector<int32_t> best(feat2_Count);
-    sift_hip_ctx* ctx = default_context();
+    sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
     check(ctx, sift_hip_match_u8(ctx, q.data(), (int)feat2_Count, r.data(), (int)feat1_Count, matchTh,
                                  sift_amd::options().ratio_form, best.data(), nullptr, nullptr), "sift_hip_match_u8");
     size_t accepted = 0;
@@ -287,7 +310,8 @@ void Stitching::Check(float matchTh) {
         std::vector<int32_t> idx(owner.size() + 1);
         float H9[9];
         int32_t n_in = -1;
-        sift_hip_ctx* ctx = default_context();
+        sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
         check(ctx, sift_hip_ransac_homog_pairs(ctx, xyuv.data(), (int)owner.size(), 4, 0.005f, 3.f,
                                                sift_amd::ransac_seed(), H9, idx.data(), &n_in, nullptr),
               "sift_hip_ransac_homog_pairs");

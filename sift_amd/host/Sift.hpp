@@ -34,6 +34,17 @@ namespace sift_amd {
 // Process-wide GPU context used by the classes below (device = $SIFT_HIP_DEVICE or 0).
 // Throws std::runtime_error when the library cannot get a gfx950 device.
 sift_hip_ctx* default_context();
+// The classes below share that one context, which like every sift_hip_ctx serves one caller at
+// a time: each of their calls into the library holds this lock for its duration, so objects may
+// be used from several threads (their GPU work is then serialised).
+class ContextUse {
+public:
+    ContextUse();
+    ~ContextUse();
+    ContextUse(const ContextUse&) = delete;
+    ContextUse& operator=(const ContextUse&) = delete;
+    sift_hip_ctx* ctx;
+};
 // Overrides for parameters the reference fixes at compile time.
 struct Options {
     int octaves = 0;    // 0 = reference's automatic count (Sift.cpp:130-139)

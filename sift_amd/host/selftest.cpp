@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <vector>
 
 #include "Sift.hpp"
@@ -124,7 +126,23 @@ int main(int argc, char** argv) {
             sx += fea3.FeatStart[i].img_pt.x;
             sy += fea3.FeatStart[i].img_pt.y;
         }
-        printf("{\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
+        // two Sift objects driven from two threads at once share the process-wide context under its lock
+        bool threads_equal = true;
+        {
+            Sift ta(img1), tb(img2);
+            std::thread t1([&] { for (int i = 0; i < 3; i++) ta.pyramid(); });
+            std::thread t2([&] { for (int i = 0; i < 3; i++) tb.pyramid(); });
+            t1.join();
+            t2.join();
+            threads_equal = ta.feaNum == fea1.feaNum && tb.feaNum == fea2.feaNum;
+            for (size_t i = 0; threads_equal && i < ta.feaNum; i++)
+                threads_equal = ta.FeatStart[i].x == fea1.FeatStart[i].x && ta.FeatStart[i].y == fea1.FeatStart[i].y &&
+                                !std::memcmp(ta.FeatStart[i].descr, fea1.FeatStart[i].descr, sizeof ta.FeatStart[i].descr);
+            for (size_t i = 0; threads_equal && i < tb.feaNum; i++)
+                threads_equal = !std::memcmp(tb.FeatStart[i].descr, fea2.FeatStart[i].descr, sizeof tb.FeatStart[i].descr);
+        }
+        printf("{\"threads_equal\": %s, ", threads_equal ? "true" : "false");
+        printf("\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
                "\"sub_sum_y\": %.6f, \"ransac_equal\": %s, \"ransac_num\": %d, \"homog\": [",
                fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy, ransac_equal ? "true" : "false",
                match.RANSAC_num);

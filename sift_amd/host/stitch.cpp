@@ -20,7 +20,8 @@ void check(sift_hip_ctx* ctx, int rc, const char* what) {
 void _WarpPerspective(const Raw& src, Raw& dst, const std::vector<float>& H) {
     if (H.size() < 9) throw std::runtime_error("_WarpPerspective: homography needs 9 values");
     if (dst.RGB.empty() || src.RGB.empty()) return;  // the reference's loops do not run
-    sift_hip_ctx* ctx = sift_amd::default_context();
+    sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
     check(ctx, sift_hip_warp_perspective(ctx, src.RGB.data(), src.getCol(), src.getRow(), H.data(), dst.RGB.data(),
                                          dst.getCol(), dst.getRow()),
           "sift_hip_warp_perspective");
@@ -29,7 +30,8 @@ void _WarpPerspective(const Raw& src, Raw& dst, const std::vector<float>& H) {
 void warping(const std::vector<Raw>& inputArrays, float FL2, std::vector<Raw>& Output, std::vector<fpoint>& upedge,
              std::vector<fpoint>& downedge) {
     Output.resize(inputArrays.size());
-    sift_hip_ctx* ctx = sift_amd::default_context();
+    sift_amd::ContextUse use;
+    sift_hip_ctx* ctx = use.ctx;
     for (size_t idx = 0; idx < inputArrays.size(); idx++) {
         const Raw& image = inputArrays[idx];
         Output[idx] = Raw((size_t)image.getCol(), (size_t)image.getRow());

@@ -52,6 +52,21 @@ for o, d in zip(outs, douts):
 best, d1, d2 = ctx.match_u8(q, r, 0.5, 0)
 assert np.array_equal(outs[0], best) and np.array_equal(outs[1], d1) and np.array_equal(outs[2], d2)
 assert (best >= 0).sum() >= 20
+# the ragged form (per-rank counts on the host, padded gather + compaction) on the same communicator
+counts = np.array([nr], np.int32)
+for o, d in zip(outs, douts):
+    o[:] = -5
+    assert hip.hipMemcpy(d, o.ctypes.data_as(C.c_void_p), o.nbytes, H2D) == 0
+rc = ctx.lib.sift_hip_match_u8_sharded_ragged(ctx.h, comm, 1, 0, dq, nq, dr, counts.ctypes.data_as(C.c_void_p), 0.5, 0,
+                                              douts[0], douts[1], douts[2])
+assert rc == 0, (rc, ctx.lib.sift_hip_last_error(ctx.h))
+ctx.synchronize()
+for o, d in zip(outs, douts):
+    assert hip.hipMemcpy(o.ctypes.data_as(C.c_void_p), d, o.nbytes, D2H) == 0
+assert np.array_equal(outs[0], best) and np.array_equal(outs[1], d1) and np.array_equal(outs[2], d2)
+bad = np.array([-1], np.int32)
+assert ctx.lib.sift_hip_match_u8_sharded_ragged(ctx.h, comm, 1, 0, dq, nq, dr, bad.ctypes.data_as(C.c_void_p), 0.5, 0,
+                                                douts[0], douts[1], douts[2]) == sift_amd.capi.ERR_ARG
 rccl.ncclCommDestroy(comm)
 for d in [dq, dr] + douts:
     hip.hipFree(d)

@@ -43,6 +43,7 @@ def test_cpp_classes_equal_c_abi_and_oracle(tmp_path, sift, oracle):
     b = sift_amd.blob_image(256, 192, seed=1, shift_x=-8)
     info, f1, f2, m = run_selftest(tmp_path, a, b, 0.5)
     assert info["file_same"] is True
+    assert info["threads_equal"] is True  # two Sift objects in two threads share the context under its lock
     fo, _ = oracle.extract(a)
     assert len(f1) == len(fo) and np.array_equal(f1["x"], fo["x"]) and np.array_equal(f1["sita"], fo["sita"])
     fa, _ = sift.extract(a)

@@ -74,18 +74,22 @@ def run_oracle(d, seed, m=4, p_bad=0.005, tol=3.0):
 
 
 def test_min_inliers_matches_float_restatement(host):
-    # the product evaluates the reference's formula in double; the float32 sums of the
-    # restatement may move the threshold by one where two terms straddle it
-    worst = 0
-    for n in list(range(4, 120)) + [150, 200, 257, 400]:
+    # up to 8192 matches the product accumulates the reference's float sums in the reference's order:
+    # equal to the float32 restatement; beyond that it evaluates the formula in double (lgamma) and
+    # may land one off where two terms straddle the threshold
+    for n in list(range(4, 120)) + [150, 200, 257, 400, 1000]:
         a = host.sift_host_ransac_min_inliers(n, 4, 0.10, 0.005)
         b = ro.calc_min_inliers(n, 4, 0.10, 0.005)
-        worst = max(worst, abs(a - b))
-        assert abs(a - b) <= 1, (n, a, b)
+        assert a == b, (n, a, b)
+    for m in (5, 8):
+        assert host.sift_host_ransac_min_inliers(300, m, 0.10, 0.005) == ro.calc_min_inliers(300, m, 0.10, 0.005)
     assert host.sift_host_ransac_min_inliers(4, 4, 0.10, 0.005) == 5  # never reachable with 4 matches
+    # the two evaluations of the product agree to one at their seam
+    a, b = host.sift_host_ransac_min_inliers(8192, 4, 0.10, 0.005), host.sift_host_ransac_min_inliers(8193, 4, 0.10, 0.005)
+    assert 0 <= b - a <= 2
     # sanity of the values themselves: grows slowly with n, well below n
-    v = [host.sift_host_ransac_min_inliers(n, 4, 0.10, 0.005) for n in (50, 500, 5000)]
-    assert v[0] < v[1] < v[2] and v[2] < 5000 * 0.2
+    v = [host.sift_host_ransac_min_inliers(n, 4, 0.10, 0.005) for n in (50, 500, 5000, 50000)]
+    assert v[0] < v[1] < v[2] < v[3] and v[2] < 5000 * 0.2 and v[3] < 50000 * 0.15
 
 
 HOMS = {
@@ -148,3 +152,54 @@ def test_repeated_points_are_skipped_not_fatal(host):
     Ho, fin, _ = run_oracle(d, 11)
     assert n_in > 0 and np.array_equal(idx, fin)
     np.testing.assert_allclose(H, Ho, rtol=2e-4, atol=1e-6)
+
+
+def _pairs(pts, mpts):
+    """Feature-style inputs (all at octave scale 1, every feature matched to its own partner)."""
+    n = len(pts)
+    one = np.ones(n, np.float32)
+    return dict(x2=pts[:, 0].astype(np.int32), y2=pts[:, 1].astype(np.int32), size2=one,
+                x1=mpts[:, 0].astype(np.int32), y1=mpts[:, 1].astype(np.int32), size1=one.copy(),
+                match=np.arange(n, dtype=np.int32))
+
+
+def test_consensus_exactly_at_the_minimum_is_accepted_and_one_less_is_not(host):
+    """xform.cpp:101 accepts in_max >= in_min: planted inliers (an exact integer translation) numbering
+    exactly the minimum consensus give a model, one fewer gives none.  The other matches point far away."""
+    n = 120
+    in_min = host.sift_host_ransac_min_inliers(n, 4, 0.10, 0.005)
+    rng = np.random.default_rng(3)
+    for planted_n, want_model in ((in_min, True), (in_min - 1, False)):
+        pts = np.stack([rng.permutation(900)[:n] + 50, rng.permutation(700)[:n] + 50], axis=1).astype(np.float32)
+        mpts = pts + np.array([31.0, -17.0], np.float32)
+        # wrong partners: unrelated positions in a far-away region, so no model explains more than a few of them
+        mpts[planted_n:] = np.stack([rng.permutation(3000)[: n - planted_n] + 5000,
+                                     rng.permutation(3000)[: n - planted_n] + 4000], axis=1).astype(np.float32)
+        n_in, H, idx = run_host(host, _pairs(pts, mpts), seed=11)
+        if want_model:
+            assert n_in == in_min and np.array_equal(np.sort(idx), np.arange(in_min))
+            assert np.allclose(H.reshape(3, 3), [[1, 0, 31], [0, 1, -17], [0, 0, 1]], atol=2e-3)
+        else:
+            assert n_in == -1
+
+
+def test_collinear_and_coincident_samples_are_skipped_not_scored(host):
+    """Departure from the reference, pinned here: a sample whose 8 x 8 system is rank deficient
+    (collinear points, two matches at one position) is skipped, where cvSolve(CV_SVD) would return a
+    minimum-norm model and score it.  Most matches below lie on one line (so most samples are
+    degenerate) and map by a translation; the off-line matches make non-degenerate samples possible.
+    The loop must still find the translation, and a set with ONLY collinear matches yields no model."""
+    rng = np.random.default_rng(5)
+    t = rng.permutation(800)[:150].astype(np.float32)
+    line = np.stack([t + 40, 2 * t + 25], axis=1)
+    off = np.stack([rng.uniform(50, 1500, 40), rng.uniform(50, 900, 40)], axis=1).astype(np.float32)
+    off = np.floor(off)
+    pts = np.concatenate([line, off]).astype(np.float32)
+    pts[7] = pts[3]  # two features at one position
+    mpts = pts + np.array([12.0, 9.0], np.float32)
+    n_in, H, idx = run_host(host, _pairs(pts, mpts), seed=2)
+    assert n_in == len(pts)
+    assert np.allclose(H.reshape(3, 3), [[1, 0, 12], [0, 1, 9], [0, 0, 1]], atol=5e-3)
+    only_line = _pairs(line, line + np.array([12.0, 9.0], np.float32))
+    n_in, _, _ = run_host(host, only_line, seed=2)
+    assert n_in == -1

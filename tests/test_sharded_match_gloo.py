@@ -93,3 +93,38 @@ def test_frames_shard_round_robin_and_counts_gather(tmp_path):
     want = np.array([100 + 3 * k for k in range(7)], np.int32)
     for rank in range(2):
         assert np.array_equal(np.load(os.path.join(str(tmp_path), f"c{rank}.npy")), want)
+
+
+def test_ragged_offsets_of_the_c_abi_match_the_concatenation():
+    """sift_hip_ragged_offsets (host arithmetic of sift_hip_match_u8_sharded_ragged): rank k's
+    reference i sits at offsets[k] + i of the rank-ordered concatenation without padding, which is
+    the order sift_amd.sharded.all_gather_refs builds."""
+    import ctypes as C
+
+    import numpy as np
+
+    import sift_amd
+    from sift_amd import capi
+
+    lib = sift_amd.load_library()
+    rng = np.random.default_rng(4)
+    for nranks in (1, 2, 3, 8):
+        counts = rng.integers(0, 50, nranks).astype(np.int32)
+        off = np.zeros(nranks + 1, np.int64)
+        largest = lib.sift_hip_ragged_offsets(counts.ctypes.data_as(C.c_void_p), nranks, off.ctypes.data_as(C.c_void_p))
+        assert largest == int(counts.max())
+        # the padded gather, squeezed: what the device copies do
+        shards = [np.full((int(c), 1), k, np.int32) + 1000 * np.arange(int(c))[:, None] for k, c in enumerate(counts)]
+        padded = np.zeros((nranks, max(largest, 1), 1), np.int32) - 1
+        for k, sh in enumerate(shards):
+            padded[k, : len(sh)] = sh
+        squeezed = np.full((int(off[-1]), 1), -7, np.int32)
+        for k in range(nranks):
+            squeezed[off[k]: off[k] + counts[k]] = padded[k, : counts[k]]
+        assert np.array_equal(squeezed, np.concatenate(shards) if off[-1] else squeezed[:0])
+        assert off[-1] == counts.sum()
+    bad = np.array([3, -1], np.int32)
+    off = np.zeros(3, np.int64)
+    assert lib.sift_hip_ragged_offsets(bad.ctypes.data_as(C.c_void_p), 2, off.ctypes.data_as(C.c_void_p)) == capi.ERR_ARG
+    huge = np.array([2 ** 31 - 1, 5], np.int32)
+    assert lib.sift_hip_ragged_offsets(huge.ctypes.data_as(C.c_void_p), 2, off.ctypes.data_as(C.c_void_p)) == capi.ERR_LIMIT
