@@ -248,6 +248,21 @@ int sift_hip_warp_cylinder(sift_hip_ctx* ctx, const uint8_t* src_rgb, int w, int
 int sift_hip_warp_cylinder_dev(sift_hip_ctx* ctx, const uint8_t* d_src_rgb, int w, int h, float focal,
                                uint8_t* d_out_rgb, float* d_upedge, float* d_downedge);
 
+/* ---- multi-band blend of the stitcher: replaces multiBandBlend, Sift/stitch/Blend.cpp:638-740
+ * (call site: blen2img, Blend.cpp:999-1006).  l_rgb (lw x lh) and r_rgb (rw x rh) are the two
+ * cylindrically projected images, interleaved 8-bit RGB; the right image lies dx columns into
+ * the left one's right edge and dy rows against its bottom edge (alignMatch's offsets; dy < 0:
+ * against its top edge).  The dx x |dy| overlap of both is cut out, its black border extended,
+ * decomposed into five-level Laplacian pyramids (5-tap Gaussian, the reference's bicubic
+ * resampler), blended level by level, collapsed and written back into BOTH images where both
+ * were non-black.  1 <= dx <= 16384, 1 <= |dy| <= 16384. */
+int sift_hip_multiband_blend(sift_hip_ctx* ctx, uint8_t* l_rgb, int lw, int lh, uint8_t* r_rgb, int rw, int rh, int dx,
+                             int dy);
+/* Both images in device memory; runs on the context's stream (one short host wait for the upload
+ * of its constants). */
+int sift_hip_multiband_blend_dev(sift_hip_ctx* ctx, uint8_t* d_l_rgb, int lw, int lh, uint8_t* d_r_rgb, int rw, int rh,
+                                 int dx, int dy);
+
 /* ---- measurement ------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; totals are kept per kernel class. */
@@ -266,7 +281,8 @@ enum {
     SIFT_HIP_K_BLUR_COL_SMALL = 11,
     SIFT_HIP_K_RANSAC = 12, /* pair gather, sample fits, consensus counts */
     SIFT_HIP_K_WARP = 13,   /* perspective and cylindrical warps */
-    SIFT_HIP_K_COUNT = 14
+    SIFT_HIP_K_BLEND = 14,  /* multi-band blend */
+    SIFT_HIP_K_COUNT = 15
 };
 int sift_hip_profile(sift_hip_ctx* ctx, int enable);
 /* Synchronises, then fills ms[k] = summed kernel time and launches[k] = launch

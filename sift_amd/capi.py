@@ -29,7 +29,7 @@ FEAT_DTYPE = np.dtype(
 assert FEAT_DTYPE.itemsize == 156
 
 KERNEL_CLASSES = ("resample", "blur_row", "blur_col", "detect", "compact", "orient", "emit", "descr", "match", "gray",
-                  "blur_row_small", "blur_col_small", "ransac", "warp")
+                  "blur_row_small", "blur_col_small", "ransac", "warp", "blend")
 
 OK, ERR_ARG, ERR_NOSPC, ERR_HIP, ERR_NOMEM, ERR_SAME, ERR_NODEVICE, ERR_LIMIT = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -127,6 +127,8 @@ def load_library() -> C.CDLL:
         "sift_hip_warp_perspective_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, fp, vp, C.c_int, C.c_int]),
         "sift_hip_warp_cylinder": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
         "sift_hip_warp_cylinder_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
+        "sift_hip_multiband_blend": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sift_hip_multiband_blend_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
         "sift_hip_kernel_class_name": (C.c_char_p, [C.c_int]),
@@ -392,6 +394,13 @@ class SiftHip:
         down = np.zeros((w, 2), np.float32)
         self._check(self.lib.sift_hip_warp_cylinder(self.h, _ptr(src), w, h, focal, _ptr(out), _ptr(up), _ptr(down)))
         return out, up, down
+
+    def multiband_blend(self, l_rgb: np.ndarray, r_rgb: np.ndarray, dx: int, dy: int):
+        """multiBandBlend (stitch/Blend.cpp:638-740): both (rows, cols, 3) uint8 images are updated in place."""
+        for a in (l_rgb, r_rgb):
+            assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3 and a.flags.c_contiguous
+        self._check(self.lib.sift_hip_multiband_blend(self.h, _ptr(l_rgb), l_rgb.shape[1], l_rgb.shape[0], _ptr(r_rgb),
+                                                      r_rgb.shape[1], r_rgb.shape[0], dx, dy))
 
     # ---- measurement ----------------------------------------------------------------
     def profile(self, enable: bool):

@@ -621,7 +621,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all,
                       &ctx->ransac.blk, &ctx->ransac.pairs, &ctx->ransac.src, &ctx->ransac.flags, &ctx->ransac.samples,
                       &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best,
-                      &ctx->warp_src, &ctx->warp_dst, &ctx->warp_edges};
+                      &ctx->warp_src, &ctx->warp_dst, &ctx->warp_edges, &ctx->blend_ws, &ctx->blend_l, &ctx->blend_r};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
@@ -1099,6 +1099,40 @@ int sift_hip_warp_cylinder(sift_hip_ctx* ctx, const uint8_t* src_rgb, int w, int
     return check_async(ctx, "warp_cylinder");
 }
 
+static bool blend_args_bad(int lw, int lh, int rw, int rh, int dx, int dy) {
+    return warp_size_bad(lw, lh) || warp_size_bad(rw, rh) || dx < 1 || dx > 16384 || dy == 0 || dy > 16384 || dy < -16384;
+}
+
+int sift_hip_multiband_blend_dev(sift_hip_ctx* ctx, uint8_t* d_l_rgb, int lw, int lh, uint8_t* d_r_rgb, int rw, int rh,
+                                 int dx, int dy) {
+    if (bad_ctx(ctx) || !d_l_rgb || !d_r_rgb || d_l_rgb == d_r_rgb || blend_args_bad(lw, lh, rw, rh, dx, dy))
+        return SIFT_HIP_ERR_ARG;
+    int rc;
+    {
+        ProfScope ps(ctx, SIFT_HIP_K_BLEND, ctx->stream);
+        rc = run_multiband_blend(ctx, d_l_rgb, lw, lh, d_r_rgb, rw, rh, dx, dy);
+    }
+    if (rc) return rc;
+    return check_async(ctx, "multiband_blend launch");
+}
+
+int sift_hip_multiband_blend(sift_hip_ctx* ctx, uint8_t* l_rgb, int lw, int lh, uint8_t* r_rgb, int rw, int rh, int dx,
+                             int dy) {
+    if (bad_ctx(ctx) || !l_rgb || !r_rgb || l_rgb == r_rgb || blend_args_bad(lw, lh, rw, rh, dx, dy)) return SIFT_HIP_ERR_ARG;
+    const size_t lb = (size_t)lw * lh * 3, rb = (size_t)rw * rh * 3;
+    int rc;
+    if ((rc = ensure(ctx, ctx->blend_l, lb))) return rc;
+    if ((rc = ensure(ctx, ctx->blend_r, rb))) return rc;
+    hipMemcpyAsync(ctx->blend_l.p, l_rgb, lb, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(ctx->blend_r.p, r_rgb, rb, hipMemcpyHostToDevice, ctx->stream);
+    rc = sift_hip_multiband_blend_dev(ctx, (uint8_t*)ctx->blend_l.p, lw, lh, (uint8_t*)ctx->blend_r.p, rw, rh, dx, dy);
+    if (rc) return rc;
+    hipMemcpyAsync(l_rgb, ctx->blend_l.p, lb, hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(r_rgb, ctx->blend_r.p, rb, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "multiband_blend")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "multiband_blend");
+}
+
 static int ransac_args_bad(sift_hip_ctx* ctx, const void* q, int nq, const void* r, int nr, const void* best, int m,
                            float p_badxform, float err_tol, const int32_t* n_in) {
     if (bad_ctx(ctx) || nq < 0 || nr < 0 || !n_in || (nq > 0 && (!q || !best)) || (nr > 0 && !r)) return 1;
@@ -1182,7 +1216,7 @@ int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset
 const char* sift_hip_kernel_class_name(int k) {
     static const char* names[SIFT_HIP_K_COUNT] = {"resample", "blur_row", "blur_col", "detect", "compact", "orient",
                                                   "emit",     "descr",    "match",    "gray",   "blur_row_small",
-                                                  "blur_col_small", "ransac", "warp"};
+                                                  "blur_col_small", "ransac", "warp", "blend"};
     return (k >= 0 && k < SIFT_HIP_K_COUNT) ? names[k] : "?";
 }
 

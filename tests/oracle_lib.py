@@ -51,7 +51,44 @@ class Oracle:
         o.orc_match_u8.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]
         o.orc_warp_perspective.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]
         o.orc_warp_cylinder.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]
+        o.orc_multiband_blend.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        o.orc_align_match.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float, vp]
+        o.orc_get_focal.argtypes = [vp, C.c_size_t, C.c_size_t]
+        o.orc_get_focal.restype = C.c_float
+        o.orc_blend_canvas_size.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        o.orc_blend_compose.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
         self.o = o
+
+    def multiband_blend(self, l_rgb, r_rgb, dx, dy):
+        """multiBandBlend (Blend.cpp:638-740); returns updated copies of both images."""
+        l = np.array(l_rgb, np.uint8, copy=True, order="C")
+        r = np.array(r_rgb, np.uint8, copy=True, order="C")
+        self.o.orc_multiband_blend(_p(l), l.shape[1], l.shape[0], _p(r), r.shape[1], r.shape[0], dx, dy)
+        return l, r
+
+    def align_match(self, size1, size2, a_xy, b_xy, FL):
+        """alignMatch (Blend.cpp:745-825): a = consensus features (image 2), b = their matches (image 1)."""
+        a = np.ascontiguousarray(a_xy, np.float32)
+        b = np.ascontiguousarray(b_xy, np.float32)
+        ax, ay, bx, by = (np.ascontiguousarray(v) for v in (a[:, 0], a[:, 1], b[:, 0], b[:, 1]))
+        out = np.zeros(2, np.int32)
+        self.o.orc_align_match(size1[0], size1[1], size2[0], size2[1], _p(ax), _p(ay), _p(bx), _p(by), len(a), FL, _p(out))
+        return int(out[0]), int(out[1])
+
+    def get_focal(self, H9, size1, size2):
+        H = None if H9 is None else np.ascontiguousarray(H9, np.float32).reshape(9)
+        return float(self.o.orc_get_focal(_p(H), size1, size2))
+
+    def blend_compose(self, w0, w1, dx, dy):
+        """The tail of blen2img (Blend.cpp:999-1133) on the two projected images: (canvas, w0, w1 after the blend)."""
+        a = np.array(w0, np.uint8, copy=True, order="C")
+        b = np.array(w1, np.uint8, copy=True, order="C")
+        size = np.zeros(2, np.int32)
+        self.o.orc_blend_canvas_size(a.shape[1], a.shape[0], b.shape[1], b.shape[0], dx, dy, _p(size))
+        canvas = np.zeros((int(size[1]), int(size[0]), 3), np.uint8)
+        self.o.orc_blend_compose(_p(a), a.shape[1], a.shape[0], _p(b), b.shape[1], b.shape[0], dx, dy, _p(canvas),
+                                 int(size[0]), int(size[1]))
+        return canvas, a, b
 
     def warp_perspective(self, src_rgb, H, dst_rgb):
         """_WarpPerspective (stitch.cpp:106-141); returns the updated copy of dst_rgb."""
