@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/sift_hip.h"
+#include "Blend.hpp"
 
 namespace sift_amd {
 
@@ -323,8 +324,9 @@ void Stitching::Check(float matchTh) {
             RANSAC_num = n_in;
         }
     }
-#ifdef SIFT_AMD_WITH_CONSUMERS
-    ImgRaw dst;
-    blen2img(img1, img2, dst, HomogMat, RANSAC_feat, RANSAC_num);
-#endif
+    // blen2img (Sift.cpp:697) for colour pairs with a model; the reference then writes the panorama to
+    // a BMP file, which is left to the caller here
+    Panorama = ImgRaw();
+    if (HomogMat.size() == 9 && RANSAC_num >= 2 && img1.bitCount == 24 && img2.bitCount == 24)
+        blen2img(img1, img2, Panorama, HomogMat, RANSAC_feat, RANSAC_num);
 }

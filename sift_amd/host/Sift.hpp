@@ -97,8 +97,9 @@ public:
     // Then ransac_xform (xform.hpp; on the GPU unless options().ransac_on_gpu is 0)
     // over those matches; its results stay in the three members below, which the
     // reference keeps as locals and prints.
-    // Blending is the reference's own code, called only when this file is built
-    // with SIFT_AMD_WITH_CONSUMERS.
+    // Then, for 24-bit images with a model, blen2img (Blend.hpp; projection and multi-band
+    // blend on the GPU); the panorama stays in the member below (the reference writes it to
+    // "dataResult\\N.bmp", Sift.cpp:699-701: file output is the caller's business here).
     void Check(float matchTh = NN_SQ_DIST_RATIO_THR);
     // The matching step of Check() alone; returns the number of accepted matches.
     size_t Match(float matchTh = NN_SQ_DIST_RATIO_THR);
@@ -106,6 +107,7 @@ public:
     std::vector<float> HomogMat;     // image 2 -> image 1, row-major 3x3; empty if RANSAC found no model
     Feature** RANSAC_feat = nullptr; // consensus features (of image 2); owned
     int RANSAC_num = 0;
+    ImgRaw Panorama;                 // what blen2img produced; empty for gray images or without a model
 
 private:
     Feature *feat1, *feat2;

@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 
+#include "Blend.hpp"
 #include "Sift.hpp"
 #include "stitch.hpp"
 
@@ -141,7 +142,18 @@ int main(int argc, char** argv) {
             for (size_t i = 0; threads_equal && i < tb.feaNum; i++)
                 threads_equal = !std::memcmp(tb.FeatStart[i].descr, fea2.FeatStart[i].descr, sizeof tb.FeatStart[i].descr);
         }
-        printf("{\"threads_equal\": %s, ", threads_equal ? "true" : "false");
+        // Check() went on to blen2img for colour pairs: <out.bin>.pano = int32 cols, rows + the float canvas
+        if (match.Panorama.size() > 0) {
+            FILE* pf = fopen((std::string(argv[2]) + ".pano").c_str(), "wb");
+            if (!pf) { perror("open panorama output"); return 2; }
+            const int32_t dim[2] = {(int32_t)match.Panorama.width, (int32_t)match.Panorama.height};
+            fwrite(dim, 4, 2, pf);
+            fwrite(match.Panorama.raw_img.data(), 4, match.Panorama.raw_img.size(), pf);
+            fclose(pf);
+        }
+        printf("{\"threads_equal\": %s, \"pano\": [%u, %u], \"focal\": %.9g, ", threads_equal ? "true" : "false",
+               match.Panorama.width, match.Panorama.height,
+               match.HomogMat.size() == 9 ? getFocal(match.HomogMat, img1.size(), img2.size()) : 0.f);
         printf("\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
                "\"sub_sum_y\": %.6f, \"ransac_equal\": %s, \"ransac_num\": %d, \"homog\": [",
                fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy, ransac_equal ? "true" : "false",

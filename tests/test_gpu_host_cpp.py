@@ -142,3 +142,24 @@ def test_plumbing_config_rgb_pair_640x480(tmp_path, sift, oracle):
         up_all.append(w_up)
         down_all.append(w_down)
     assert np.array_equal(take_pts(), np.concatenate(up_all)) and np.array_equal(take_pts(), np.concatenate(down_all))
+    # ... and Check() went on to blen2img: the panorama equals the restated pipeline (focal length from
+    # the homography, cylindrical projection, alignment of the consensus matches, multi-band blend,
+    # canvas assembly), value for value
+    Hf = np.array(info["homog"], np.float32)
+    focal = oracle.get_focal(Hf, 640 * 480 * 3, 640 * 480 * 3)
+    assert np.float32(info["focal"]) == np.float32(focal)
+    cons = np.array(info["ransac_feat"], np.int64)
+    a_xy = np.stack([f2["x"][cons] / f2["size"][cons], f2["y"][cons] / f2["size"][cons]], axis=1).astype(np.float32)
+    p1 = f1[m[cons]]
+    b_xy = np.stack([p1["x"] / p1["size"], p1["y"] / p1["size"]], axis=1).astype(np.float32)
+    dx, dy = oracle.align_match((640, 480), (640, 480), a_xy, b_xy, focal)
+    c1, _, _ = oracle.warp_cylinder(u1, focal)
+    c2, _, _ = oracle.warp_cylinder(u2, focal)
+    want_canvas, _, _ = oracle.blend_compose(c1, c2, dx, dy)
+    praw = open(str(tmp_path / "out.bin") + ".pano", "rb").read()
+    pc, pr = np.frombuffer(praw[:8], np.int32)
+    pano = np.frombuffer(praw[8:], np.float32).reshape(pr, pc, 3)
+    print("panorama %d x %d, offsets (%d, %d), focal %.1f" % (pc, pr, dx, dy, focal))
+    assert info["pano"] == [int(pc), int(pr)] and (pr, pc) == want_canvas.shape[:2]
+    assert np.array_equal(pano, (want_canvas.astype(np.float64) / 255.0).astype(np.float32))
+    assert want_canvas.any() and abs(dx - (640 - 40)) <= 3  # image 2 = image 1 moved 40 px: 600 columns in common
