@@ -39,9 +39,24 @@ def main():
     Hr, fin, in_min = ransac_oracle.ransac_xform(xyuv[:, :2], xyuv[:, 2:], 4, 0.005, 3.0, 77)
     warped = orc.warp_perspective(src, Hw, canvas)
     cyl, up, down = orc.warp_cylinder(src, 120.0)
+    # multiBandBlend / alignMatch / getFocal (oracle/blend_oracle.cpp) on a small smooth pair
+    from scipy import ndimage
+    rng = np.random.default_rng(99)
+    wide = ndimage.gaussian_filter(rng.random((72, 200, 3)).astype(np.float32), (3, 3, 0))
+    wide = ((wide - wide.min()) / (wide.max() - wide.min()) * 235 + 15).astype(np.uint8)
+    bl, br = np.ascontiguousarray(wide[:, :120]), np.ascontiguousarray(wide[:, 69:189])
+    bl[:4], br[-5:] = 0, 0
+    blend_l, blend_r = orc.multiband_blend(bl, br, 51, 71)
+    Hb = np.array([0.99, 0.01, 60.0, -0.02, 1.01, 2.0, 3e-5, 2e-5, 1.0], np.float32)
+    a_xy = np.stack([rng.uniform(5, 60, 12), rng.uniform(5, 65, 12)], axis=1).astype(np.float32)
+    b_xy = (a_xy + np.array([69.0, 0.5], np.float32)).astype(np.float32)
+    bfocal = np.float32(orc.get_focal(Hb, 120 * 72 * 3, 120 * 72 * 3))
+    balign = np.array(orc.align_match((120, 72), (120, 72), a_xy, b_xy, float(bfocal)), np.int32)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "stitch_oracle.npz"), xyuv=xyuv, ransac_seed=77,
                         ransac_H=Hr, ransac_inliers=fin.astype(np.int32), ransac_in_min=in_min, src=src, canvas=canvas,
-                        Hw=Hw, warped=warped, focal=np.float32(120.0), cyl=cyl, cyl_up=up, cyl_down=down)
+                        Hw=Hw, warped=warped, focal=np.float32(120.0), cyl=cyl, cyl_up=up, cyl_down=down,
+                        blend_in_l=bl, blend_in_r=br, blend_dx=51, blend_dy=71, blend_l=blend_l, blend_r=blend_r,
+                        blend_H=Hb, blend_a=a_xy, blend_b=b_xy, blend_focal=bfocal, blend_align=balign)
     print("consensus", len(fin), "of", len(xyuv), "in_min", in_min)
 
 

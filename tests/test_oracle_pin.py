@@ -223,3 +223,21 @@ def test_stitch_golden_regression_guard(oracle):
     assert np.array_equal(oracle.warp_perspective(g["src"], g["Hw"], g["canvas"]), g["warped"])
     cyl, up, down = oracle.warp_cylinder(g["src"], float(g["focal"]))
     assert np.array_equal(cyl, g["cyl"]) and np.array_equal(up, g["cyl_up"]) and np.array_equal(down, g["cyl_down"])
+
+
+def test_blend_oracle_regression_fixture():
+    """oracle/blend_oracle.cpp (multiBandBlend, alignMatch, getFocal restated; parity unpinned) still gives
+    what it gave when tests/golden/stitch_oracle.npz was generated."""
+    import os
+
+    from tests.oracle_lib import Oracle
+
+    orc = Oracle()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stitch_oracle.npz"))
+    lo, ro = orc.multiband_blend(g["blend_in_l"], g["blend_in_r"], int(g["blend_dx"]), int(g["blend_dy"]))
+    assert np.array_equal(lo, g["blend_l"]) and np.array_equal(ro, g["blend_r"])
+    assert (lo != g["blend_in_l"]).sum() > 1000
+    f = np.float32(orc.get_focal(g["blend_H"], 120 * 72 * 3, 120 * 72 * 3))
+    assert f == g["blend_focal"]
+    assert list(orc.align_match((120, 72), (120, 72), g["blend_a"], g["blend_b"], float(f))) == list(g["blend_align"])
+    assert orc.get_focal(None, 10, 30) == 20.0  # no homography: the mean of the two sizes
