@@ -53,7 +53,18 @@ typedef struct sift_hip_params {
     int32_t blur_mode;   /* 0 = exact: float product, double accumulation in tap order
                             (imglib/imglib.cpp:85-117); 1 = fast: fp32 FMA accumulation */
     float contr_thr;     /* SIFT_CONTR_THR (0.05), used only when subpixel = 1 */
-    int32_t reserved;
+    int32_t textbook;    /* 0 = the reference's pyramid and descriptor, quirks included (parity mode, default);
+                            1 = quality mode, which departs from the reference where its own notes call the
+                            code unverified (update.md:9-10): every Gaussian level is blurred from the one
+                            below by the INCREMENT that brings it to sigma0 * sqrt(2)^i (the reference applies
+                            the absolute sigma again at every level), with the same sigmas in octave pixels
+                            at every octave (the reference doubles them per octave on top of halving the
+                            image); orientation windows of radius 4.5 sigma weighted by 1.5 sigma; the
+                            descriptor frame rotated by the orientation in RADIANS (the reference feeds
+                            degrees to cos/sin, which breaks rotation invariance), sized by the un-truncated
+                            sigma, and normalised, clamped at 0.2 and normalised again before quantisation
+                            (both normalisations are no-ops in the reference); sub-pixel refinement on.
+                            Results are not comparable with the reference's; see the accuracy test. */
 } sift_hip_params;
 
 /* One keypoint + descriptor: the fields of `struct Feature` (imagedata.hpp:63-86)

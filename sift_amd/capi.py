@@ -43,7 +43,7 @@ class _Params(C.Structure):
         ("subpixel", C.c_int32),
         ("blur_mode", C.c_int32),
         ("contr_thr", C.c_float),
-        ("reserved", C.c_int32),
+        ("textbook", C.c_int32),
     ]
 
 
@@ -58,10 +58,11 @@ class SiftParams:
     subpixel: int = 0
     blur_mode: int = 0
     contr_thr: float = 0.05
+    textbook: int = 0  # 1 = quality mode (incremental sigmas, radians, normalised descriptor); not the reference's output
 
     def _c(self) -> _Params:
         return _Params(self.octaves, self.intvls, self.sigma0, self.dx_thr, self.subpixel, self.blur_mode,
-                       self.contr_thr, 0)
+                       self.contr_thr, self.textbook)
 
 
 class SiftHipError(RuntimeError):

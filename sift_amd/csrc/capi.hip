@@ -123,7 +123,7 @@ static int pyramid_octaves(size_t width, size_t height) {
 
 static bool same_params(const sift_hip_params& a, const sift_hip_params& b) {
     return a.octaves == b.octaves && a.intvls == b.intvls && a.sigma0 == b.sigma0 && a.dx_thr == b.dx_thr &&
-           a.subpixel == b.subpixel && a.blur_mode == b.blur_mode && a.contr_thr == b.contr_thr;
+           a.subpixel == b.subpixel && a.blur_mode == b.blur_mode && a.contr_thr == b.contr_thr && a.textbook == b.textbook;
 }
 
 // Everything Sift::pyramid derives from (w, h, params) before touching pixels.
@@ -137,8 +137,11 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
     const int pyWidth = prm.intvls + 3;
     const int octvs = prm.octaves > 0 ? prm.octaves : pyramid_octaves((size_t)w, (size_t)h);
     // cos/sin of the 36 possible orientations, taken in DEGREES as radians (Sift.cpp:351-352)
-    for (int k = 0; k < 36; k++) pl.table.push_back(std::cos((float)(k * 10)));
-    for (int k = 0; k < 36; k++) pl.table.push_back(std::sin((float)(k * 10)));
+    // (quality mode: the orientation in radians)
+    const bool tb = prm.textbook != 0;
+    auto frame_angle = [&](int k) -> float { return tb ? (float)(k * 10) * (float)(3.14159265358979323846 / 180.0) : (float)(k * 10); };
+    for (int k = 0; k < 36; k++) pl.table.push_back(std::cos(frame_angle(k)));
+    for (int k = 0; k < 36; k++) pl.table.push_back(std::sin(frame_angle(k)));
     // Sift.cpp:369-372 wraps (gradient angle - ori) into [0, 2*pi) by repeated float
     // additions of 2*pi; with ori up to 350 that is up to 56 roundings on a coarse
     // grid.  The net shift those additions give an angle of 0 is tabulated per
@@ -147,7 +150,7 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
         const float PI2 = (float)(2.f * 3.14159265358979323846);
         double shift[36];
         for (int k = 0; k < 36; k++) {
-            const float x0 = 0.f - (float)(k * 10);
+            const float x0 = 0.f - frame_angle(k);
             float x = x0;
             while (x < 0.f) x += PI2;
             while (x >= PI2) x -= PI2;
@@ -166,8 +169,16 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
         if (oc.W < 2 || oc.H < 2) break;
         for (int i = 0; i < pyWidth; i++) {
             // Sift.cpp:152 (level 0) and :155 (levels >= 1)
-            const float s = (i == 0) ? prm.sigma0 * coef : prm.sigma0 * powf(std::sqrt(2.0), (size_t)i) * coef;
-            std::vector<float> g = gau_matrix(s, 0);
+            float s = (i == 0) ? prm.sigma0 * coef : prm.sigma0 * powf(std::sqrt(2.0), (size_t)i) * coef;
+            float s_blur = s;  // the reference blurs level i-1 with the absolute sigma of level i (Sift.cpp:157)
+            if (tb) {
+                // quality mode: the same sigma ladder in octave pixels at every octave, reached by increments;
+                // the resampled image counts as blurred by 0.5 source pixels
+                s = prm.sigma0 * powf(std::sqrt(2.0), (size_t)i);
+                const float below = i == 0 ? std::max(0.5f * curr_size, 0.1f) : oc.sigma.back();
+                s_blur = std::sqrt(std::max(s * s - below * below, 0.01f));
+            }
+            std::vector<float> g = gau_matrix(s_blur, 0);
             oc.sigma.push_back(s);
             oc.tap_off.push_back((int)pl.table.size());
             oc.tap_len.push_back((int)g.size());
@@ -175,9 +186,15 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
             while (pl.table.size() & 7) pl.table.push_back(0.f);
         }
         for (int li = 1; li <= prm.intvls; li++) {
-            const size_t r = curr_size * 3. * 1.5 * (li + 1);                           // Sift.cpp:177
-            const float cs = prm.sigma0 * powf(std::sqrt(2.0), (size_t)li) * coef;      // Sift.cpp:183
-            std::vector<float> g = gau_matrix(cs, r * 2 + 1);                           // Sift.cpp:267
+            size_t r = curr_size * 3. * 1.5 * (li + 1);                                 // Sift.cpp:177
+            float cs = prm.sigma0 * powf(std::sqrt(2.0), (size_t)li) * coef;            // Sift.cpp:183
+            float ws_ = cs;                                                             // Sift.cpp:267
+            if (tb) {  // quality mode: radius 3 x 1.5 sigma, weights of 1.5 sigma, sigma of the layer in octave pixels
+                cs = prm.sigma0 * powf(std::sqrt(2.0), (size_t)li);
+                ws_ = 1.5f * cs;
+                r = (size_t)std::lround(3.0 * ws_);
+            }
+            std::vector<float> g = gau_matrix(ws_, r * 2 + 1);
             oc.radius.push_back((int)r);
             oc.curr_sigma.push_back(cs);
             oc.wts_off.push_back((int)pl.table.size());
@@ -194,7 +211,8 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
     std::vector<LayerConsts> lc;
     for (const OctavePlan& oc : pl.oct)
         for (int li = 0; li < prm.intvls; li++)
-            lc.push_back(LayerConsts{oc.radius[li], oc.wts_off[li], oc.curr_sigma[li], (float)(int)oc.curr_sigma[li]});
+            lc.push_back(LayerConsts{oc.radius[li], oc.wts_off[li], oc.curr_sigma[li],
+                                     tb ? oc.curr_sigma[li] : (float)(int)oc.curr_sigma[li]});
     rc = ensure(ctx, ctx->layer_consts, std::max<size_t>(1, lc.size()) * sizeof(LayerConsts));
     if (rc) return rc;
     if (!lc.empty() &&
@@ -332,18 +350,21 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
             const LayerConsts* d_lc = (const LayerConsts*)ctx->layer_consts.p + (size_t)oi * prm.intvls;
             launch_detect(ctx, ws, oi, PX, oc.W, oc.H, prm.intvls, d_lc, thr, cand_cap,
                           lazy ? (const float*)ctx->table.p + oc.tap_off[prm.intvls + 2] : nullptr, top_K);
-            if (prm.subpixel) launch_refine(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc, prm.contr_thr);
+            // (quality mode: the contrast bar per interval, the rule the reference's header keeps commented out, matrix.hpp:181)
+            if (prm.subpixel)
+                launch_refine(ctx, ws, PX, oc.W, oc.H, prm.intvls, d_lc,
+                              prm.textbook ? prm.contr_thr / (float)prm.intvls : prm.contr_thr);
             launch_orient(ctx, ws, PX, oc.W, d_lc, (const float*)ctx->table.p);
-            launch_emit(ctx, ws, oi, oc.curr_size, d_lc, feat_cap, prm.subpixel != 0);
+            launch_emit(ctx, ws, oi, oc.curr_size, d_lc, feat_cap, prm.subpixel != 0, prm.textbook != 0);
             int max_window = 1;
             for (int li = 0; li < prm.intvls; li++) {
                 // descriptor radius of Sift.cpp:357 for this layer's integer-truncated sigma
-                const float hw = 3.f * (float)(int)oc.curr_sigma[li];
+                const float hw = 3.f * (prm.textbook ? oc.curr_sigma[li] : (float)(int)oc.curr_sigma[li]);
                 const int R = (int)(hw * std::sqrt(2.f) * (4 + 1.f) * 0.5f + 0.5f);
                 max_window = std::max(max_window, (2 * R + 1) * (2 * R + 1));
             }
             launch_descr(ctx, ws, PX, oc.W, oc.H, (const float*)ctx->table.p, feat_cap,
-                         want_hist ? (float*)ws.hist.p : nullptr, max_window);
+                         want_hist ? (float*)ws.hist.p : nullptr, max_window, prm.textbook != 0);
         }
         return r;
     };
@@ -434,6 +455,8 @@ static int checked_params(const sift_hip_params* params, int w, int h, sift_hip_
     if (prm->intvls < 1 || prm->intvls > 8 || prm->octaves < 0 || prm->octaves > 24 || !(prm->sigma0 > 0.f))
         return SIFT_HIP_ERR_ARG;
     if (prm->subpixel != 0 && prm->subpixel != 1) return SIFT_HIP_ERR_ARG;
+    if (prm->textbook != 0 && prm->textbook != 1) return SIFT_HIP_ERR_ARG;
+    if (prm->textbook) prm->subpixel = 1;  // the quality mode refines every keypoint
     // octave 0 is the image doubled in both directions; the kernels index one level with 32 bits
     if ((long long)w * h * 4 >= (1ll << 31)) return SIFT_HIP_ERR_LIMIT;
     return SIFT_HIP_OK;
@@ -651,7 +674,7 @@ void sift_hip_default_params(sift_hip_params* p) {
     p->subpixel = 0;
     p->blur_mode = 0;
     p->contr_thr = 0.05f;  // SIFT_CONTR_THR
-    p->reserved = 0;
+    p->textbook = 0;
 }
 
 const char* sift_hip_strerror(int s) {

@@ -68,7 +68,7 @@ __device__ __forceinline__ void clip_row(int& jlo, int& jhi, float p, float q, f
 __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
                                                    const float* __restrict__ cs, sift_hip_feat* __restrict__ feat,
                                                    int feat_cap, const int* __restrict__ counters,
-                                                   float* __restrict__ hist_out) {
+                                                   float* __restrict__ hist_out, int textbook) {
     __shared__ unsigned long long hist[NCOPY * HSTRIDE];
     __shared__ int s_off[RCH + 1];  // first sample number of each window row of the pass
     __shared__ int s_lo[RCH];       // first column of each row
@@ -86,17 +86,21 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
     for (int fi = counters[CNT_OCT_BEGIN] + blockIdx.x; fi < end; fi += gridDim.x) {
         const sift_hip_feat* f = feat + fi;
         const int kai = f->kai, r = f->y, c = f->x, sita = f->sita;
-        const float ori = (float)sita;
-        const float scl = (float)(int)f->sigmaOCT;
+        // Quality mode: the frame angle in radians and the un-truncated sigma.  The orientation
+        // histogram measures its angles with the row axis pointing down (Sift.cpp:262), the
+        // descriptor's gradients with it pointing up (Sift.cpp:306): the same direction is -sita here.
+        const float ori = textbook ? -(float)sita * (float)(3.14159265358979323846 / 180.0) : (float)sita;
+        const float scl = textbook ? f->sigmaOCT : (float)(int)f->sigmaOCT;
         const float* img = gau + (size_t)kai * PX;
         for (int t = tid; t < NCOPY * HSTRIDE; t += nthr) hist[t] = 0ull;
         const int ob36 = sita / 10;
-        const float cos_t = cs[ob36];
-        const float sin_t = cs[36 + ob36];
+        const float cos_t = textbook ? cosf(ori) : cs[ob36];
+        const float sin_t = textbook ? sinf(ori) : cs[36 + ob36];
         // The reference brings atan2 - ori (ori up to 350 "radians") into [0, 2*pi)
         // by adding 2*pi one float addition at a time (Sift.cpp:369-372); the sum of
         // those roundings for this orientation is folded into wrap_hi + wrap_lo.
-        const float wrap_hi = cs[72 + ob36], wrap_lo = cs[108 + ob36];
+        // (quality mode: atan2 - ori lies in (-pi, 3*pi): the two conditional steps below suffice)
+        const float wrap_hi = textbook ? 0.f : cs[72 + ob36], wrap_lo = textbook ? 0.f : cs[108 + ob36];
         const float hist_width = 3.f * scl;
         const float inv_hw = 1.f / hist_width;
         const float L = 2.5f * hist_width;
@@ -211,17 +215,38 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
         }
         // hist_to_descr: clamp at 0.2 (double compare), x512 in double, truncate, min 255
         if (tid < 64) {
-            unsigned char q[2];
+            float hv[2];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const int b = tid * 2 + t;
                 unsigned long long acc = 0ull;
 #pragma unroll
                 for (int k = 0; k < NCOPY; k++) acc += hist[k * HSTRIDE + b];
-                float hv = (float)((double)acc * (1.0 / 1073741824.0));
-                if ((double)hv > 0.2) hv = (float)0.2;
-                if (hist_out) hist_out[(size_t)fi * 128 + b] = hv;
-                const int iv = (int)(512.0 * (double)hv);
+                hv[t] = (float)((double)acc * (1.0 / 1073741824.0));
+            }
+            if (textbook) {
+                // quality mode: unit length, clamp at 0.2, unit length again (what normalize_descr was
+                // meant to do, Sift.cpp:389-414); sums over the wave in a fixed order
+                for (int pass = 0; pass < 2; pass++) {
+                    float ss = hv[0] * hv[0] + hv[1] * hv[1];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+                    const float inv = ss > 0.f ? 1.f / sqrtf(ss) : 0.f;
+                    hv[0] *= inv;
+                    hv[1] *= inv;
+                    if (pass == 0) {
+                        hv[0] = fminf(hv[0], 0.2f);
+                        hv[1] = fminf(hv[1], 0.2f);
+                    }
+                }
+            }
+            unsigned char q[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                float v = hv[t];
+                if (!textbook && (double)v > 0.2) v = (float)0.2;
+                if (hist_out) hist_out[(size_t)fi * 128 + tid * 2 + t] = v;
+                const int iv = (int)(512.0 * (double)v);
                 q[t] = (unsigned char)min(255, iv);
             }
             unsigned char* d = feat[fi].descr + tid * 2;
@@ -233,14 +258,14 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
 }
 
 void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const float* d_cs, int feat_cap,
-                  float* d_hist, int max_window) {
+                  float* d_hist, int max_window, bool textbook) {
     ProfScope ps(ctx, SIFT_HIP_K_DESCR, ws.stream);
     // threads per feature: about 48 window samples per thread for the octave's largest window
     int nthr = ((max_window / 48) + 63) / 64 * 64;
     nthr = std::max(64, std::min(1024, nthr));
     const int blocks = 256 * std::max(2, 2048 / nthr);
     hipLaunchKernelGGL(descr_kernel, dim3(blocks), dim3(nthr), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H,
-                       d_cs, (sift_hip_feat*)ws.feat.p, feat_cap, (const int*)ws.counters.p, d_hist);
+                       d_cs, (sift_hip_feat*)ws.feat.p, feat_cap, (const int*)ws.counters.p, d_hist, textbook ? 1 : 0);
 }
 
 }  // namespace sifthip

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const Cand* __restrict__ cand
                                                    sift_hip_feat* __restrict__ feat, int feat_cap,
                                                    const int* __restrict__ counters,
                                                    const float4* __restrict__ cand_sub,
-                                                   float* __restrict__ feat_sub) {
+                                                   float* __restrict__ feat_sub, int textbook) {
     const int ncand = counters[CNT_NCAND];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
         unsigned long long m = cmask[i];
@@ -689,7 +689,16 @@ __global__ __launch_bounds__(256) void emit_kernel(const Cand* __restrict__ cand
                 f->x = cd.x;
                 f->y = cd.y;
                 f->mm = cmm[(size_t)i * 36 + bin];
-                f->sita = bin * 10;
+                int sita = bin * 10;  // the reference reports the lower edge of the 10-degree bin (Sift.cpp:287)
+                if (textbook) {
+                    // quality mode: the bin's centre moved by the vertex of the parabola through the peak and its neighbours
+                    const float l = cmm[(size_t)i * 36 + (bin + 35) % 36], c0 = cmm[(size_t)i * 36 + bin],
+                                r = cmm[(size_t)i * 36 + (bin + 1) % 36];
+                    const float den = l - 2.f * c0 + r;
+                    const float off = den < 0.f ? fminf(fmaxf(0.5f * (l - r) / den, -0.5f), 0.5f) : 0.f;
+                    sita = ((int)lroundf(10.f * ((float)bin + 0.5f + off)) + 360) % 360;
+                }
+                f->sita = sita;
                 if (feat_sub) {
                     const float4 o = cand_sub[i];
                     feat_sub[(size_t)pos * 3 + 0] = o.x;
@@ -763,7 +772,7 @@ void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerCo
 }
 
 void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap,
-                 bool with_sub) {
+                 bool with_sub, bool textbook) {
     ProfScope ps(ctx, SIFT_HIP_K_EMIT, ws.stream);
     hipLaunchKernelGGL(emit_scan_kernel, dim3(1), dim3(1024), 0, ws.stream,
                        (const unsigned long long*)ws.cand_mask.p, (int*)ws.cand_off.p, (int*)ws.counters.p,
@@ -772,7 +781,7 @@ void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, cons
                        (const unsigned long long*)ws.cand_mask.p, (const float*)ws.cand_mm.p,
                        (const int*)ws.cand_off.p, d_lc, curr_size, (sift_hip_feat*)ws.feat.p, feat_cap,
                        (const int*)ws.counters.p, (const float4*)ws.cand_sub.p,
-                       with_sub ? (float*)ws.feat_sub.p : nullptr);
+                       with_sub ? (float*)ws.feat_sub.p : nullptr, textbook ? 1 : 0);
 }
 
 }  // namespace sifthip

@@ -165,10 +165,10 @@ void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
                    float contr_thr);
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table);
 void launch_emit(sift_hip_ctx* ctx, OctWs& ws, int octave, float curr_size, const LayerConsts* d_lc, int feat_cap,
-                 bool with_sub);
+                 bool with_sub, bool textbook);
 // descriptor.hip; max_window: sample count (2R+1)^2 of the octave's largest descriptor window
 void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const float* d_cs, int feat_cap,
-                  float* d_hist, int max_window);
+                  float* d_hist, int max_window, bool textbook);
 // match.hip
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
               int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);

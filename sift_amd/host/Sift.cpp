@@ -180,6 +180,7 @@ void Sift::pyramid() {
     prm.octaves = sift_amd::options().octaves;
     prm.subpixel = sift_amd::options().subpixel;
     prm.blur_mode = sift_amd::options().blur_mode;
+    prm.textbook = sift_amd::options().textbook;
     // The records come back into a page-locked buffer kept beside the shared context (direct
     // DMA); like the context it is only touched while `use` holds the context lock.
     static sift_hip_feat* buf = nullptr;

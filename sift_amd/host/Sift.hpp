@@ -50,6 +50,7 @@ struct Options {
     int octaves = 0;    // 0 = reference's automatic count (Sift.cpp:130-139)
     int subpixel = 0;   // 1 = Lowe refinement (matrix.hpp:140-196), off in the reference
     int blur_mode = 0;  // 0 = exact reference arithmetic
+    int textbook = 0;   // 1 = quality mode of sift_hip_params (not the reference's output)
     int ratio_form = 0; // 0 = d0 < d1*th (Sift.cpp:576), 1 = (d0/d1) < th (Sift.cpp:563)
     int ransac_on_gpu = 1; // Stitching::Check: 1 = sift_hip_ransac_homog, 0 = ransac_xform on the CPU (same result)
 };

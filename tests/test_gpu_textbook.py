@@ -1,0 +1,103 @@
+"""Accuracy study of the quality ("textbook") mode against the parity mode: how many features of an
+image are found again, with a matching descriptor, in a rotated / scaled / shifted copy of it.
+
+The parity mode reproduces the reference, which feeds the orientation in DEGREES to cos/sin: its
+descriptor frame is a fixed pseudo-random function of the orientation bin, so a rotated copy (whose
+keypoints fall into other bins) gets unrelated descriptors.  The quality mode rotates the frame by the
+orientation in radians and normalises the descriptor; it must survive rotation and scale, and lose
+nothing on the translated pairs the reference's panoramas consist of."""
+import numpy as np
+import pytest
+
+import sift_amd
+from sift_amd import SiftParams
+
+pytestmark = pytest.mark.gpu
+
+
+def transformed(img, angle_deg, scale, shift):
+    """img seen through p_out = scale * R(angle) * (p_in - c) + c + shift; returns (image, forward map)."""
+    from scipy import ndimage
+
+    h, w = img.shape
+    c = np.array([(w - 1) / 2.0, (h - 1) / 2.0])
+    a = np.deg2rad(angle_deg)
+    R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) * scale  # acts on (x, y)
+    Rinv = np.linalg.inv(R)
+    # affine_transform wants input = M @ output + off, in (row, col) order
+    M = Rinv[::-1, ::-1]
+    off = (c - Rinv @ (c + np.asarray(shift, float)))[::-1]
+    out = ndimage.affine_transform(img, M, offset=off, order=3, mode="nearest").astype(np.float32)
+    fwd = lambda p: (p - c) @ R.T + c + np.asarray(shift, float)  # noqa: E731
+    return np.clip(out, 0.0, 1.0), fwd
+
+
+def correct_matches(ctx, a, b, fwd, prm, ratio=0.6, tol=3.0):
+    fa, _ = ctx.extract(a, prm)
+    fb, _ = ctx.extract(b, prm)
+    if len(fa) < 2 or len(fb) < 2:
+        return 0, 0, len(fa), len(fb)
+    best, _, _ = ctx.match_u8(fb["descr"], fa["descr"], ratio, 0)
+    sel = np.nonzero(best >= 0)[0]
+    pa = np.stack([fa["x"] / fa["size"], fa["y"] / fa["size"]], axis=1)[best[sel]]
+    pb = np.stack([fb["x"] / fb["size"], fb["y"] / fb["size"]], axis=1)[sel]
+    err = np.linalg.norm(fwd(pa) - pb, axis=1)
+    return int((err <= tol).sum()), len(sel), len(fa), len(fb)
+
+
+CASES = [("shift 40 px", 0.0, 1.0, (-40.0, 6.0)), ("rotation 25 deg", 25.0, 1.0, (0.0, 0.0)),
+         ("rotation 70 deg", 70.0, 1.0, (0.0, 0.0)), ("scale 1.3", 0.0, 1.3, (0.0, 0.0)),
+         ("rotation 40 deg + scale 0.8", 40.0, 0.8, (10.0, -5.0))]
+
+
+def textured(w, h, seed):
+    """Anisotropic content (isotropic blobs look the same in any descriptor frame): band-passed noise at
+    several scales on top of the usual blob field."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(seed)
+    tex = np.zeros((h, w), np.float64)
+    for sigma, weight in ((1.5, 1.0), (3.0, 1.0), (6.0, 1.2), (12.0, 1.5)):
+        n = ndimage.gaussian_filter(rng.standard_normal((h, w)), sigma)
+        tex += weight * n / n.std()
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    return (0.6 * tex + 0.4 * sift_amd.blob_image(w, h, seed=seed)).astype(np.float32)
+
+
+def test_quality_mode_survives_rotation_and_scale_where_the_parity_mode_does_not(sift):
+    img = textured(800, 600, seed=3)
+    rows = []
+    for name, ang, sc, sh in CASES:
+        b, fwd = transformed(img, ang, sc, sh)
+        res = {}
+        for mode in (0, 1):
+            res[mode] = correct_matches(sift, img, b, fwd, SiftParams(octaves=4, textbook=mode))
+        rows.append((name, res))
+        print("%-28s parity: %4d correct of %4d accepted (%d / %d features) | quality: %4d correct of %4d accepted (%d / %d features)"
+              % ((name,) + res[0] + res[1]))
+    by = dict(rows)
+    # translation (the reference's use case): both modes work
+    assert by["shift 40 px"][0][0] >= 300 and by["shift 40 px"][1][0] >= 300
+    for name in ("rotation 25 deg", "rotation 70 deg", "scale 1.3", "rotation 40 deg + scale 0.8"):
+        ok_q, acc_q = by[name][1][0], by[name][1][1]
+        ok_p = by[name][0][0]
+        assert ok_q >= 100 and ok_q >= 0.8 * acc_q, (name, by[name])   # many matches, few wrong ones
+        if "rotation" in name:
+            assert ok_q >= 3 * max(ok_p, 1), (name, by[name])          # the parity mode is not rotation invariant
+
+
+def test_quality_mode_descriptors_are_unit_length_and_deterministic(sift):
+    img = textured(640, 480, seed=9)
+    prm = SiftParams(textbook=1)
+    f, h = sift.extract(img, prm, want_hist=True)
+    f2, _ = sift.extract(img, prm)
+    assert len(f) > 300 and f.tobytes() == f2.tobytes()
+    n = np.sqrt((h.astype(np.float64) ** 2).sum(axis=1))
+    assert np.abs(n - 1.0).max() < 1e-5
+    assert (h <= 0.2 * 1.7).all()  # clamped at 0.2 before the second normalisation
+    # octave sigmas: the same ladder in octave pixels at every octave
+    assert {round(float(v), 3) for v in np.unique(f["sigmaOCT"])} <= {2.263, 3.2, 4.525}
+    # the parity mode is untouched by the new field
+    fp, _ = sift.extract(img, SiftParams())
+    fp0, _ = sift.extract(img, SiftParams(textbook=0))
+    assert fp.tobytes() == fp0.tobytes()
