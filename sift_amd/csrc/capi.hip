@@ -73,6 +73,7 @@ void prof_begin(sift_hip_ctx* ctx, int cls, hipStream_t st) {
             hipEventCreate(e);
         }
     }
+    ev.st = st;
     hipEventRecord(ev.a, st);
     ctx->events.push_back(ev);
 }
@@ -401,10 +402,31 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
 static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow,
                           hipStream_t st = nullptr, bool join_side = true) {
     if (!st) st = ctx->stream;
-    if (join_side && ctx->side_busy &&
-        (!hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)") ||
-         !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream2), "extract (second side stream)")))
-        return SIFT_HIP_ERR_HIP;
+    int early = 0;  // records of octave 0 whose copy is already under way
+    if (join_side && ctx->side_busy) {
+        // Octave 0 holds three quarters of the features and its stream is usually done while the
+        // small octaves still drain: read its count and start its copy (on the copy stream) now.
+        // (worth its extra counter read, about 10 us, only for frames with a long drain: 4 Mpixel and more)
+        const bool plain = !hist && ctx->plan.prm.subpixel == 0 && st == ctx->stream &&
+                           (size_t)ctx->plan.oct[0].W * ctx->plan.oct[0].H >= ((size_t)16 << 20);
+        if (plain) {
+            if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int),
+                                            hipMemcpyDeviceToHost, st), "read counters") ||
+                !hip_ok(ctx, hipStreamSynchronize(st), "extract (octave 0)"))
+                return SIFT_HIP_ERR_HIP;
+            int found0 = ctx->h_counters[G_OCT_CAND];
+            if (ctx->lanes[0].lazy_top) found0 = std::max(found0, ctx->h_counters[G_OCT_CAND_TOP]);
+            if (found0 <= ctx->cand_cap) {
+                early = std::max(0, std::min(ctx->h_counters[G_OCT_FEATS], cap));
+                if (early > 0 && !hip_ok(ctx, hipMemcpyAsync(out, ctx->lanes[0].feat.p, (size_t)early * sizeof(sift_hip_feat),
+                                                             hipMemcpyDeviceToHost, ctx->copy_stream), "read features"))
+                    return SIFT_HIP_ERR_HIP;
+            }
+        }
+        if (!hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)") ||
+            !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream2), "extract (second side stream)"))
+            return SIFT_HIP_ERR_HIP;
+    }
     if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
                                     st), "read counters"))
         return SIFT_HIP_ERR_HIP;
@@ -415,7 +437,10 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
         if (ctx->lanes[oi].lazy_top) found = std::max(found, ctx->h_counters[G_OCT_CAND_TOP + oi]);
         if (found > ctx->cand_cap) *cand_overflow = std::max(*cand_overflow, found);
     }
-    if (*cand_overflow) return SIFT_HIP_OK;
+    if (*cand_overflow) {
+        if (early > 0) hipStreamSynchronize(ctx->copy_stream);  // the caller's array is rewritten by the next attempt
+        return SIFT_HIP_OK;
+    }
     const int noct = (int)ctx->plan.oct.size();
     const bool with_sub = ctx->plan.prm.subpixel != 0;
     ctx->h_sub.clear();
@@ -430,7 +455,8 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
         const int cnt = ctx->h_counters[G_OCT_FEATS + oi];
         const int m = std::max(0, std::min(cnt, cap - copied));  // the octave's buffer holds at most cap
         if (m > 0) {
-            if (!hip_ok(ctx, hipMemcpyAsync(out + copied, ctx->lanes[oi].feat.p, (size_t)m * sizeof(sift_hip_feat),
+            if (!(oi == 0 && early == m) &&
+                !hip_ok(ctx, hipMemcpyAsync(out + copied, ctx->lanes[oi].feat.p, (size_t)m * sizeof(sift_hip_feat),
                                             hipMemcpyDeviceToHost, st), "read features"))
                 return SIFT_HIP_ERR_HIP;
             if (hist && !hip_ok(ctx, hipMemcpyAsync(hist + (size_t)copied * 128, ctx->lanes[oi].hist.p,
@@ -447,6 +473,7 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
     }
     *n = (int)std::min<long long>(total, INT32_MAX);
     if (copied > 0 && !hip_ok(ctx, hipStreamSynchronize(st), "read features")) return SIFT_HIP_ERR_HIP;
+    if (early > 0 && !hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "read features (octave 0)")) return SIFT_HIP_ERR_HIP;
     return total > cap ? SIFT_HIP_ERR_NOSPC : SIFT_HIP_OK;
 }
 
@@ -593,6 +620,9 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     ctx->device = device;
     // SIFT_HIP_SERIAL=1: all octaves on one stream (clean per-kernel durations under a tracer)
     if (const char* e = std::getenv("SIFT_HIP_SERIAL")) ctx->force_serial = (e[0] == '1');
+    // SIFT_HIP_TIMELINE=1: sift_hip_profile_read prints when each launch group began and ended on
+    // which stream (events only, the streams stay concurrent: what a tracer's host overhead hides)
+    if (const char* e = std::getenv("SIFT_HIP_TIMELINE")) ctx->timeline = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_FULL_TOP")) ctx->full_top_level = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("SIFT_HIP_NSIDE")) ctx->n_side = (e[0] == '1') ? 1 : 2;
@@ -1218,6 +1248,23 @@ int sift_hip_profile(sift_hip_ctx* ctx, int enable) {
 int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset) {
     if (bad_ctx(ctx)) return SIFT_HIP_ERR_ARG;
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "profile_read")) return SIFT_HIP_ERR_HIP;
+    if (ctx->timeline && !ctx->events.empty()) {
+        hipStreamSynchronize(ctx->side_stream);
+        hipStreamSynchronize(ctx->side_stream2);
+        // a frame starts at a "resample" group on the main stream; times are relative to the last one
+        size_t first = 0;
+        for (size_t i = 0; i < ctx->events.size(); i++)
+            if (ctx->events[i].cls == SIFT_HIP_K_RESAMPLE && ctx->events[i].st == ctx->stream) first = i;
+        for (size_t i = first; i < ctx->events.size(); i++) {
+            const auto& e = ctx->events[i];
+            float t0 = 0.f, t1 = 0.f;
+            hipEventElapsedTime(&t0, ctx->events[first].a, e.a);
+            hipEventElapsedTime(&t1, ctx->events[first].a, e.b);
+            const int q = e.st == ctx->stream ? 0 : (e.st == ctx->side_stream ? 1 : 2);
+            std::fprintf(stderr, "timeline q%d %*s%8.1f + %7.1f  %s\n", q, 4 * q, "", t0 * 1e3f, (t1 - t0) * 1e3f,
+                         sift_hip_kernel_class_name(e.cls));
+        }
+    }
     for (auto& e : ctx->events) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) {

@@ -115,9 +115,10 @@ struct sift_hip_ctx {
     // profiling
     bool profiling = false;
     bool force_serial = false;
+    bool timeline = false;  // SIFT_HIP_TIMELINE=1: events around every launch group with the streams left concurrent
     bool full_top_level = false;  // SIFT_HIP_FULL_TOP=1: build the last Gaussian level as an image (A/B measurements)
     int side_priority = 1;          // 1: the small-octave stream is created with the urgent priority
-    struct Ev { int cls; hipEvent_t a, b; };
+    struct Ev { int cls; hipEvent_t a, b; hipStream_t st; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> free_events;
     float prof_ms[SIFT_HIP_K_COUNT] = {0};
@@ -136,8 +137,8 @@ void prof_end(sift_hip_ctx* ctx, hipStream_t st);
 struct ProfScope {
     sift_hip_ctx* c;
     hipStream_t st;
-    ProfScope(sift_hip_ctx* ctx, int cls, hipStream_t s) : c(ctx), st(s) { if (c->profiling) prof_begin(c, cls, st); }
-    ~ProfScope() { if (c->profiling) prof_end(c, st); }
+    ProfScope(sift_hip_ctx* ctx, int cls, hipStream_t s) : c(ctx), st(s) { if (c->profiling || c->timeline) prof_begin(c, cls, st); }
+    ~ProfScope() { if (c->profiling || c->timeline) prof_end(c, st); }
 };
 
 // ---- launchers (defined next to their kernels) --------------------------------

@@ -283,12 +283,6 @@ size_t Stitching::Match(float matchTh) {
     return accepted;
 }
 
-#ifdef SIFT_AMD_WITH_CONSUMERS
-// The reference's own blender (stitch/Blend.hpp:15).
-void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::vector<float>& HomogMat,
-              const Feature* const* RANSAC_feat, int RANSAC_num);
-#endif
-
 Stitching::~Stitching() { delete[] RANSAC_feat; }
 
 void Stitching::Check(float matchTh) {
@@ -313,7 +307,7 @@ void Stitching::Check(float matchTh) {
         float H9[9];
         int32_t n_in = -1;
         sift_amd::ContextUse use;
-    sift_hip_ctx* ctx = use.ctx;
+        sift_hip_ctx* ctx = use.ctx;
         check(ctx, sift_hip_ransac_homog_pairs(ctx, xyuv.data(), (int)owner.size(), 4, 0.005f, 3.f,
                                                sift_amd::ransac_seed(), H9, idx.data(), &n_in, nullptr),
               "sift_hip_ransac_homog_pairs");
