@@ -65,10 +65,11 @@ __device__ __forceinline__ void clip_row(int& jlo, int& jhi, float p, float q, f
 
 // cs: cos[36], sin[36] of the orientation (degrees read as radians), then the
 // two-float wrap constant of each orientation (see build_plan).
+template <bool textbook>
 __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ gau, size_t PX, int W, int H,
                                                    const float* __restrict__ cs, sift_hip_feat* __restrict__ feat,
                                                    int feat_cap, const int* __restrict__ counters,
-                                                   float* __restrict__ hist_out, int textbook) {
+                                                   float* __restrict__ hist_out) {
     __shared__ unsigned long long hist[NCOPY * HSTRIDE];
     __shared__ int s_off[RCH + 1];  // first sample number of each window row of the pass
     __shared__ int s_lo[RCH];       // first column of each row
@@ -215,18 +216,31 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
         }
         // hist_to_descr: clamp at 0.2 (double compare), x512 in double, truncate, min 255
         if (tid < 64) {
-            float hv[2];
+            unsigned char q[2];
+            if constexpr (!textbook) {
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int b = tid * 2 + t;
-                unsigned long long acc = 0ull;
+                for (int t = 0; t < 2; t++) {
+                    const int b = tid * 2 + t;
+                    unsigned long long acc = 0ull;
 #pragma unroll
-                for (int k = 0; k < NCOPY; k++) acc += hist[k * HSTRIDE + b];
-                hv[t] = (float)((double)acc * (1.0 / 1073741824.0));
-            }
-            if (textbook) {
+                    for (int k = 0; k < NCOPY; k++) acc += hist[k * HSTRIDE + b];
+                    float hv = (float)((double)acc * (1.0 / 1073741824.0));
+                    if ((double)hv > 0.2) hv = (float)0.2;
+                    if (hist_out) hist_out[(size_t)fi * 128 + b] = hv;
+                    const int iv = (int)(512.0 * (double)hv);
+                    q[t] = (unsigned char)min(255, iv);
+                }
+            } else {
                 // quality mode: unit length, clamp at 0.2, unit length again (what normalize_descr was
                 // meant to do, Sift.cpp:389-414); sums over the wave in a fixed order
+                float hv[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    unsigned long long acc = 0ull;
+#pragma unroll
+                    for (int k = 0; k < NCOPY; k++) acc += hist[k * HSTRIDE + tid * 2 + t];
+                    hv[t] = (float)((double)acc * (1.0 / 1073741824.0));
+                }
                 for (int pass = 0; pass < 2; pass++) {
                     float ss = hv[0] * hv[0] + hv[1] * hv[1];
 #pragma unroll
@@ -239,15 +253,11 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
                         hv[1] = fminf(hv[1], 0.2f);
                     }
                 }
-            }
-            unsigned char q[2];
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                float v = hv[t];
-                if (!textbook && (double)v > 0.2) v = (float)0.2;
-                if (hist_out) hist_out[(size_t)fi * 128 + tid * 2 + t] = v;
-                const int iv = (int)(512.0 * (double)v);
-                q[t] = (unsigned char)min(255, iv);
+                for (int t = 0; t < 2; t++) {
+                    if (hist_out) hist_out[(size_t)fi * 128 + tid * 2 + t] = hv[t];
+                    q[t] = (unsigned char)min(255, (int)(512.0 * (double)hv[t]));
+                }
             }
             unsigned char* d = feat[fi].descr + tid * 2;
             d[0] = q[0];
@@ -264,8 +274,10 @@ void launch_descr(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, const f
     int nthr = ((max_window / 48) + 63) / 64 * 64;
     nthr = std::max(64, std::min(1024, nthr));
     const int blocks = 256 * std::max(2, 2048 / nthr);
-    hipLaunchKernelGGL(descr_kernel, dim3(blocks), dim3(nthr), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H,
-                       d_cs, (sift_hip_feat*)ws.feat.p, feat_cap, (const int*)ws.counters.p, d_hist, textbook ? 1 : 0);
+    // (the quality mode is its own instance: its in-kernel sin/cos would cost the parity path registers)
+    auto kern = textbook ? descr_kernel<true> : descr_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nthr), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, H,
+                       d_cs, (sift_hip_feat*)ws.feat.p, feat_cap, (const int*)ws.counters.p, d_hist);
 }
 
 }  // namespace sifthip

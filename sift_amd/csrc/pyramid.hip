@@ -106,20 +106,39 @@ constexpr int kBigColLds = 150 * 1024;  // gfx950 lets a workgroup address 160 K
 
 // The sliding window of a thread: P input values in a ring (slot = input index
 // mod P) and one tap step over all of them: acc[p] += win[(p + u) % P] * g.
+typedef float float_pair __attribute__((ext_vector_type(2)));
+// Float accumulation (blur_mode 1): fused multiply-add, two outputs per instruction
+// (v_pk_fma_f32).  Output pair (2j, 2j+1) needs the input pair (2j+k, 2j+k+1) at tap k:
+// for even k that is a pair of ring slots (2m, 2m+1), for odd k a pair (2m+1, 2m+2), so the
+// ring is kept in both pairings and every new input is written into one pair of each.
 template <typename ACC, int P>
-struct Window {  // float accumulation (blur_mode 1): fused multiply-add
-    float v[P];
-    __device__ __forceinline__ void set(int slot, float x) { v[slot] = x; }
+struct Window {
+    float_pair e[P / 2], o[P / 2];
+    __device__ __forceinline__ void set(int slot, float x) {
+        if (slot & 1) {
+            e[slot >> 1].y = x;
+            o[slot >> 1].x = x;
+        } else {
+            e[slot >> 1].x = x;
+            o[((slot + P - 2) % P) >> 1].y = x;
+        }
+    }
     __device__ __forceinline__ void step(ACC (&acc)[P], int u, float g) const {
+        const float_pair gg = {g, g};
 #pragma unroll
-        for (int p = 0; p < P; p++) acc[p] = fmaf(v[(p + u) % P], g, acc[p]);
+        for (int j = 0; j < P / 2; j++) {
+            const float_pair in = (u & 1) ? o[(j + (u >> 1)) % (P / 2)] : e[(j + (u >> 1)) % (P / 2)];
+            float_pair a = {acc[2 * j], acc[2 * j + 1]};
+            a = __builtin_elementwise_fma(in, gg, a);
+            acc[2 * j] = a.x;
+            acc[2 * j + 1] = a.y;
+        }
     }
 };
 // Exact mode: the product is rounded to float first, as `img[..] * gau_mat[k]` is,
 // then added in double.  The slots are kept as register pairs so that one packed
 // multiply (v_pk_mul_f32, same rounding as two v_mul_f32) serves two outputs;
 // conversion and addition stay one instruction per output.
-typedef float float_pair __attribute__((ext_vector_type(2)));
 template <int P>
 struct Window<double, P> {
     float_pair v[P / 2];
@@ -525,9 +544,156 @@ static bool col_stream(hipStream_t st, const float* tmp, float* dst, int W, int 
     }
 }
 
+// ---- both passes in one launch (short kernels on large images) ----------------------
+// A 256-thread workgroup produces a 64 x 64 tile: its 64+K-1 input rows and columns go to
+// LDS once, the row pass runs over all 64+K-1 rows of the tile into a second LDS array
+// (the values the two-pass form would round to float and store in `tmp`), and the column
+// pass reads that.  Every output receives the same products in the same order as in the
+// two-pass form, so the results are identical; what changes is that the level is read
+// and written once instead of twice, at the price of (64+K-1)/64 times the row-pass
+// arithmetic.  K is a template parameter: both loops are fully unrolled.
+template <typename ACC, int K, int P>
+__device__ __forceinline__ void conv_run(const float* __restrict__ src, int stride, const float* __restrict__ taps,
+                                         ACC (&acc)[P]) {
+    Window<ACC, P> win;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        acc[p] = 0;
+        win.set(p, src[p * stride]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const float g = taps[k];
+        win.step(acc, k % P, g);
+        if (k + P < K + P - 1) win.set(k % P, src[(k + P) * stride]);
+    }
+}
+
+template <int K>
+struct FusedGeom {
+    static constexpr int T = 64;                          // tile edge
+    static constexpr int NIN = T + K - 1;                 // input rows and columns of a tile
+    static constexpr int PIN = ((NIN + 6) / 8) * 8 + 1;   // LDS pitch, 1 mod 8: 8 rows x 8 eight-column blocks hit 64 banks
+    static constexpr size_t lds_bytes = (size_t)NIN * PIN * sizeof(float);
+};
+
+template <typename ACC, int K>
+__global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
+                                                         int H, const float* __restrict__ taps) {
+    using G = FusedGeom<K>;
+    constexpr int R = K >> 1, NIN = G::NIN, PIN = G::PIN;
+    extern __shared__ float s[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    // Input tile, indices clamped as both passes of the two-pass form clamp them.  The loads go
+    // global -> LDS directly (64 consecutive words per wave instruction), so all of a wave's rows
+    // are in flight at once and cost no registers.
+    {
+        const int c0 = min(max(x0 - R + lane, 0), W - 1);
+        const int c1 = min(max(x0 - R + 64 + lane, 0), W - 1);
+        const bool second = lane + 64 < NIN;
+        for (int i = wave; i < NIN; i += 4) {
+            const float* row = in + (size_t)min(max(y0 - R + i, 0), H - 1) * W;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + c0),
+                                             (__attribute__((address_space(3))) void*)(s + i * PIN), 4, 0, 0);
+            if (second)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + c1),
+                                                 (__attribute__((address_space(3))) void*)(s + i * PIN + 64), 4, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's tile rows have landed
+    __syncthreads();
+    // Row pass: unit = (tile row, block of 8 output columns).  The eight units of a row sit in one
+    // wave, which reads every input of the row before it writes, so the results replace the
+    // inputs in place (columns 0..63 of the row).
+    for (int u = tid; u < 64 * 8; u += 256) {
+        const int row = u >> 3, xb = u & 7;
+        ACC acc[8];
+        float* d = s + row * PIN + xb * 8;
+        conv_run<ACC, K, 8>(d, 1, taps, acc);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < 8; p++) d[p] = (float)acc[p];
+    }
+    // the K-1 rows left over would fill only part of a third round of 8-column units:
+    // 4-column units spread them over twice as many threads at half the length each
+    // (pitch 1 mod 4: 4 rows x 16 four-column blocks hit 64 banks)
+    constexpr int PR = ((K - 1) * 8 <= 128 || ((K - 1) * 8 > 256 && (K - 1) * 8 <= 384)) ? 4 : 8;
+    for (int u = tid; u < (K - 1) * (64 / PR); u += 256) {
+        const int row = 64 + u / (64 / PR), xb = u % (64 / PR);
+        ACC acc[PR];
+        float* d = s + row * PIN + xb * PR;
+        conv_run<ACC, K, PR>(d, 1, taps, acc);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < PR; p++) d[p] = (float)acc[p];
+    }
+    __syncthreads();
+    // column pass: unit = (column, block of 8 output rows)
+    const int x = x0 + lane;
+    for (int yb = wave; yb < 8; yb += 4) {
+        if (y0 + yb * 8 >= H) break;  // wave-uniform
+        ACC acc[8];
+        conv_run<ACC, K, 8>(s + (yb * 8) * PIN + lane, PIN, taps, acc);
+        if (x < W) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int y = y0 + yb * 8 + p;
+                if (y < H) out[(size_t)y * W + x] = (float)acc[p];
+            }
+        }
+    }
+}
+
+template <typename ACC, int K>
+static bool launch_fused(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* dst, int W, int H,
+                         const float* d_taps) {
+    using G = FusedGeom<K>;
+    static signed char state[64] = {0};  // per device: the kernel's LDS request above 64 KB needs an opt-in
+    signed char& ok = state[ctx->device & 63];
+    if (ok == 0)
+        ok = (G::lds_bytes <= (size_t)kMaxColLds ||
+              hipFuncSetAttribute(reinterpret_cast<const void*>(&blur_fused_kernel<ACC, K>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes) == hipSuccess) ? 1 : -1;
+    if (ok != 1) return false;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_fused_kernel<ACC, K>), dim3((W + 63) / 64, (H + 63) / 64), dim3(256),
+                       G::lds_bytes, st, src, dst, W, H, d_taps);
+    return true;
+}
+
+// whether the one-launch form is the choice for this level
+template <typename ACC>
+static bool fused_wanted(int W, int H, int K) {
+    // exact arithmetic: up to 29 taps (beyond, the extra row-pass work costs more than the second
+    // trip through memory saves); float arithmetic: every length that has an instance
+    const size_t px = (size_t)W * H;
+    // (images of 16 Mpixel and more have the streaming column pass, which moves the break-even down)
+    int max_k = sizeof(ACC) == sizeof(double) ? (px >= ((size_t)16 << 20) ? 15 : 29) : 39;
+    if (const char* e = std::getenv("SIFT_BLUR_FUSED")) max_k = std::atoi(e);
+    return K <= max_k && px >= ((size_t)3 << 20) && (K == 11 || K == 15 || K == 21 || K == 29 || K == 39);
+}
+
+// true if the level was produced by the one-launch form
+template <typename ACC>
+static bool blur_fused(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* dst, int W, int H,
+                       const float* d_taps, int K) {
+    switch (K) {
+        case 11: return launch_fused<ACC, 11>(ctx, st, src, dst, W, H, d_taps);
+        case 15: return launch_fused<ACC, 15>(ctx, st, src, dst, W, H, d_taps);
+        case 21: return launch_fused<ACC, 21>(ctx, st, src, dst, W, H, d_taps);
+        case 29: return launch_fused<ACC, 29>(ctx, st, src, dst, W, H, d_taps);
+        case 39: return launch_fused<ACC, 39>(ctx, st, src, dst, W, H, d_taps);
+        default: return false;
+    }
+}
+
 template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                            const float* d_taps, int K) {
+    if (src != dst && fused_wanted<ACC>(W, H, K)) {
+        ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
+        if (blur_fused<ACC>(ctx, st, src, dst, W, H, d_taps, K)) return;
+    }
     {
         ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_ROW : SIFT_HIP_K_BLUR_ROW_SMALL, st);
         const int n_in = 64 * P + K - 1 + P;
