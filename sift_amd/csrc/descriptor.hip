@@ -26,7 +26,8 @@ namespace sifthip {
 constexpr int NCOPY = 8;
 constexpr int HSTRIDE = 129;
 constexpr float kFixScale = 1073741824.f;  // 2^30 units per 1.0; one addend is < 4
-constexpr int RCH = 1024;                  // window rows handled per pass
+constexpr int RCH = 512;                   // window rows handled per pass
+constexpr int NCHUNK = 2048;               // 64-sample chunks of a pass whose first row is tabulated
 constexpr int DU = 4;                      // samples in flight per thread
 
 // v is already scaled by kFixScale
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
                                                    float* __restrict__ hist_out) {
     __shared__ unsigned long long hist[NCOPY * HSTRIDE];
     __shared__ int s_off[RCH + 1];  // first sample number of each window row of the pass
-    __shared__ int s_lo[RCH];       // first column of each row
+    __shared__ short s_lo[RCH];     // first column of each row
+    // row of the first sample of each 64-sample chunk: a wave's 64 consecutive samples start
+    // their search for "my row" there instead of walking every row of the window
+    __shared__ unsigned short s_chunk[NCHUNK];
     // blockDim.x (a multiple of 64, chosen per octave from the window size) threads
     // share one feature; windows grow with the octave up to (2*382+1)^2 samples
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -135,11 +139,20 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
                     }
                     if (row < nr) {
                         s_off[row] = running + inc - len;
-                        s_lo[row] = jlo;
+                        s_lo[row] = (short)jlo;
                     }
                     running += __shfl(inc, 63);
                 }
                 if (lane == 0) s_off[nr] = running;
+                // (same wave: the LDS writes above are in order before these reads)
+                for (int b = 0; b < nr; b += 64) {
+                    const int row = b + lane;
+                    if (row < nr) {
+                        const int lo = s_off[row], hi = s_off[row + 1];
+                        for (int ch = (lo + 63) >> 6; ch <= ((hi - 1) >> 6) && ch < NCHUNK; ch++)
+                            if (hi > lo) s_chunk[ch] = (unsigned short)row;
+                    }
+                }
             }
             __syncthreads();
             const int total = s_off[nr];
@@ -155,6 +168,7 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
                     const int idx = idx0 + u * nthr;
                     ok[u] = idx < total;
                     if (ok[u]) {
+                        if ((idx >> 6) < NCHUNK) row = s_chunk[idx >> 6];
                         while (idx >= s_off[row + 1]) row++;
                         const int i = row0 + row - radius;
                         const int j = s_lo[row] + idx - s_off[row];
