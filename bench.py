@@ -136,15 +136,17 @@ def main():
         # writes every pixel once: 8 B per pixel.
         stage_bytes_per_px = levels * 8 + (levels - 1) * 4
         big = [p for p in px if p >= (3 << 20)]          # octaves handled by the 8-outputs-per-thread kernels
-        dom = max(("blur_col", "blur_row"), key=lambda k: prof[k][0])
+        dom = max(("blur_col", "blur_row", "blur_fused"), key=lambda k: prof[k][0])
         kname = {"blur_col": "column pass of the octaves of 3 Mpixel and more (blur_col_stream_kernel<K> at octave 0, "
                              "blur_col_kernel<double, 8> at octave 1)",
-                 "blur_row": "blur_row_kernel<double, 8>"}[dom] if args.blur_mode == 0 else None
+                 "blur_row": "blur_row_kernel<double, 8>",
+                 "blur_fused": "blur_fused_kernel<double, K> (row and column pass of a level in one launch)"}[dom] \
+            if args.blur_mode == 0 else None
         n_dom = prof[dom][1] // nprof
         avg_ms = prof[dom][0] / max(prof[dom][1], 1)
         alg_launch = 8.0 * sum(big) / max(len(big), 1)   # the class's launches differ only in tap count
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9
-        blur_keys = ("blur_row", "blur_col", "blur_row_small", "blur_col_small")
+        blur_keys = ("blur_row", "blur_col", "blur_row_small", "blur_col_small", "blur_fused")
         t_stage = sum(prof[k][0] for k in blur_keys) / nprof
         alg_stage = sum(px) * stage_bytes_per_px
         # Measured HBM traffic of the class's kernels comes from the rocprofv3 PMC passes kept under
@@ -160,7 +162,8 @@ def main():
         if os.path.exists(tpath) and (W, H, args.octaves, args.blur_mode) == (3840, 2160, 4, 0):
             tj = json.load(open(tpath))
             if tj.get("kernel_source_sha256") == src_hash:
-                want = ("blur_col_kernel<double, 8>", "blur_col_stream_kernel") if dom == "blur_col" else ("blur_row_kernel<double, 8>",)
+                want = {"blur_col": ("blur_col_kernel<double, 8>", "blur_col_stream_kernel"),
+                        "blur_row": ("blur_row_kernel<double, 8>",), "blur_fused": ("blur_fused_kernel",)}[dom]
                 kk = [v for k, v in tj["kernels"].items() if k.startswith(want)]
                 nl = sum(v["launches_per_frame"] for v in kk)
                 if kk and nl:
@@ -174,7 +177,8 @@ def main():
         # triple per SIMD (tools/microbench_valu.hip), 1024 SIMDs
         # levels built as images: the library evaluates the last level only around top-layer
         # extrema (unless the sub-pixel stage is on), which the launch count shows
-        built = (sum(prof[k][1] for k in blur_keys) // nprof) // (2 * len(px))
+        # (a level is one row-pass launch plus one column-pass launch, or one fused launch)
+        built = ((prof["blur_row"][1] + prof["blur_row_small"][1] + prof["blur_fused"][1]) // nprof) // len(px)
         taps = 0
         size = 2.0
         for o in range(args.octaves):
@@ -226,12 +230,13 @@ def main():
         pf = ctx.profile_read(reset=True)
         ctx.profile(False)
         ctx.extract_dev(d_frame, W, H, prm, out)  # back to the exact plan
-        t_fast = sum(pf[k][0] for k in ("blur_row", "blur_col", "blur_row_small", "blur_col_small")) / 3
-        launches = sum(pf[k][1] for k in ("blur_row", "blur_col", "blur_row_small", "blur_col_small")) // 3
+        fkeys = ("blur_row", "blur_col", "blur_row_small", "blur_col_small", "blur_fused")
+        t_fast = sum(pf[k][0] for k in fkeys) / 3
+        launches = sum(pf[k][1] for k in fkeys) // 3
         px = pyramid_pixels(W, H, args.octaves)
         levels = prm.intvls + 3
         alg = sum(px) * (levels * 8 + (levels - 1) * 4)
-        domf = max(("blur_col", "blur_row"), key=lambda k: pf[k][0])
+        domf = max(("blur_col", "blur_row", "blur_fused"), key=lambda k: pf[k][0])
         bigpx = [p_ for p_ in px if p_ >= (3 << 20)]
         alg_l = 8.0 * sum(bigpx) / max(len(bigpx), 1)
         avg = pf[domf][0] / max(pf[domf][1], 1)

@@ -293,7 +293,8 @@ enum {
     SIFT_HIP_K_RANSAC = 12, /* pair gather, sample fits, consensus counts */
     SIFT_HIP_K_WARP = 13,   /* perspective and cylindrical warps */
     SIFT_HIP_K_BLEND = 14,  /* multi-band blend */
-    SIFT_HIP_K_COUNT = 15
+    SIFT_HIP_K_BLUR_FUSED = 15, /* row and column pass of one level in one launch (short kernels, octaves of 3 Mpixel and more) */
+    SIFT_HIP_K_COUNT = 16
 };
 int sift_hip_profile(sift_hip_ctx* ctx, int enable);
 /* Synchronises, then fills ms[k] = summed kernel time and launches[k] = launch

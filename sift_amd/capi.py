@@ -29,7 +29,7 @@ FEAT_DTYPE = np.dtype(
 assert FEAT_DTYPE.itemsize == 156
 
 KERNEL_CLASSES = ("resample", "blur_row", "blur_col", "detect", "compact", "orient", "emit", "descr", "match", "gray",
-                  "blur_row_small", "blur_col_small", "ransac", "warp", "blend")
+                  "blur_row_small", "blur_col_small", "ransac", "warp", "blend", "blur_fused")
 
 OK, ERR_ARG, ERR_NOSPC, ERR_HIP, ERR_NOMEM, ERR_SAME, ERR_NODEVICE, ERR_LIMIT = 0, -1, -2, -3, -4, -5, -6, -7
 

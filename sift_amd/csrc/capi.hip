@@ -1286,7 +1286,7 @@ int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset
 const char* sift_hip_kernel_class_name(int k) {
     static const char* names[SIFT_HIP_K_COUNT] = {"resample", "blur_row", "blur_col", "detect", "compact", "orient",
                                                   "emit",     "descr",    "match",    "gray",   "blur_row_small",
-                                                  "blur_col_small", "ransac", "warp", "blend"};
+                                                  "blur_col_small", "ransac", "warp", "blend", "blur_fused"};
     return (k >= 0 && k < SIFT_HIP_K_COUNT) ? names[k] : "?";
 }
 

@@ -669,8 +669,12 @@ static bool fused_wanted(int W, int H, int K) {
     const size_t px = (size_t)W * H;
     // (images of 16 Mpixel and more have the streaming column pass, which moves the break-even down)
     int max_k = sizeof(ACC) == sizeof(double) ? (px >= ((size_t)16 << 20) ? 15 : 29) : 39;
-    if (const char* e = std::getenv("SIFT_BLUR_FUSED")) max_k = std::atoi(e);
-    return K <= max_k && px >= ((size_t)3 << 20) && (K == 11 || K == 15 || K == 21 || K == 29 || K == 39);
+    size_t min_px = (size_t)3 << 20;  // smaller octaves: too few 64 x 64 tiles to fill the chip
+    if (const char* e = std::getenv("SIFT_BLUR_FUSED")) {  // A/B and test switch: longest kernel, any image size
+        max_k = std::atoi(e);
+        min_px = 0;
+    }
+    return K <= max_k && px >= min_px && (K == 11 || K == 15 || K == 21 || K == 29 || K == 39);
 }
 
 // true if the level was produced by the one-launch form
@@ -691,7 +695,7 @@ template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                            const float* d_taps, int K) {
     if (src != dst && fused_wanted<ACC>(W, H, K)) {
-        ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
+        ProfScope ps(ctx, SIFT_HIP_K_BLUR_FUSED, st);
         if (blur_fused<ACC>(ctx, st, src, dst, W, H, d_taps, K)) return;
     }
     {

@@ -461,6 +461,38 @@ def test_streaming_column_pass_bit_exact_on_ragged_shapes(sift, oracle, monkeypa
     assert np.array_equal(bits(sift.gau_blur(img, 3.2)), bits(oracle.gau_blur(img, 3.2)))
 
 
+def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
+    """The one-launch form of the blur (row and column pass of a 64 x 64 tile through LDS; by
+    itself only used on octaves of 3 Mpixel and more) forced onto small and ragged images: every
+    tap count it is instantiated for, sizes that are not multiples of the tile, images smaller
+    than the kernel, one-row and one-column images; exact mode against the oracle, float mode
+    against the two-launch form."""
+    rng = np.random.default_rng(37)
+    shapes = [(200, 131), (64, 64), (1, 77), (130, 1), (65, 40), (333, 95), (129, 257)]
+    for p, K in ((1.6, 11), (2.2627418, 15), (3.2, 21), (4.5254836, 29), (6.4, 39)):
+        for i, (w, h) in enumerate(shapes):
+            img = (rng.random((h, w), dtype=np.float32) - (0.5 if i == 3 else 0.0)).astype(np.float32)
+            if i % 2:
+                img[rng.random((h, w)) < 0.3] = 0.0
+            monkeypatch.setenv("SIFT_BLUR_FUSED", "99")
+            got0 = bits(sift.gau_blur(img, p))
+            got1 = bits(sift.gau_blur(img, p, blur_mode=1))
+            monkeypatch.setenv("SIFT_BLUR_FUSED", "0")
+            assert np.array_equal(got0, bits(oracle.gau_blur(img, p))), (K, w, h)
+            assert np.array_equal(got1, bits(sift.gau_blur(img, p, blur_mode=1))), (K, w, h)
+    monkeypatch.delenv("SIFT_BLUR_FUSED", raising=False)
+    # the launch count shows the form in use: a 2048 x 1600 image takes it for its short kernels
+    img = rng.random((1600, 2048), dtype=np.float32)
+    sift.profile(True)
+    sift.profile_read(reset=True)
+    out = sift.gau_blur(img, 1.6)
+    prof = sift.profile_read(reset=True)
+    sift.profile(False)
+    assert prof["blur_fused"][1] == 1 and prof["blur_row"][1] == 0 and prof["blur_col"][1] == 0
+    monkeypatch.setenv("SIFT_BLUR_FUSED", "0")
+    assert np.array_equal(bits(out), bits(sift.gau_blur(img, 1.6)))
+
+
 def test_two_contexts_extract_concurrently(sift):
     """Two contexts on one device driven from two threads: each keeps its two streams (the
     library joins them on the host, no stream waits on another's event) and both give the

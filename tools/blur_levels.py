@@ -32,7 +32,7 @@ def timed(p):
     pr = ctx.profile_read(reset=True)
     ctx.profile(False)
     row = pr["blur_row"][0] + pr["blur_row_small"][0]
-    col = pr["blur_col"][0] + pr["blur_col_small"][0]
+    col = pr["blur_col"][0] + pr["blur_col_small"][0] + pr["blur_fused"][0]
     return out, row * 1e3, col * 1e3
 
 

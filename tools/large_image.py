@@ -34,7 +34,7 @@ ctx.profile_read()
 ctx.extract_dev(d, W, H, prm, out)
 prof = ctx.profile_read()
 ctx.profile(False)
-blur_ms = sum(prof[k][0] for k in ("blur_row", "blur_col", "blur_row_small", "blur_col_small"))
+blur_ms = sum(prof[k][0] for k in ("blur_row", "blur_col", "blur_row_small", "blur_col_small", "blur_fused"))
 px = sum((int(W * s) * int(H * s)) for s in (2, 1, .5, .25, .125, .0625)[:octaves])
 print(f"{W}x{H}, {octaves} octaves: {ms:.2f} ms per frame, {n} features, device memory in use "
       f"{(free0 - free1) / 2**30:.1f} GiB (frame included), blur stage {blur_ms:.2f} ms = "
