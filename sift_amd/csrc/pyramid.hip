@@ -584,7 +584,14 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict
     constexpr int R = K >> 1, NIN = G::NIN, PIN = G::PIN;
     extern __shared__ float s[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2: remapped so that one
+    // XCD owns a contiguous run of tiles, the halo a tile shares with its neighbours is an L2 hit
+    // instead of a second fetch over the fabric (bijective for any tile count).
+    const int ntile = gridDim.x * gridDim.y;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = ntile >> 3, r8 = ntile & 7, xcd = bid & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int x0 = (lin % (int)gridDim.x) * 64, y0 = (lin / (int)gridDim.x) * 64;
     // Input tile, indices clamped as both passes of the two-pass form clamp them.  The loads go
     // global -> LDS directly (64 consecutive words per wave instruction), so all of a wave's rows
     // are in flight at once and cost no registers.
