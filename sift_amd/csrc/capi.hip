@@ -238,25 +238,35 @@ static int get_lane(sift_hip_ctx* ctx, int oi, OctWs** out) {
 }
 
 // Gaussian levels of octave `oi` from the gray image on the device, on stream st.
-static int run_octave_pyramid(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, const float* d_gray, int oi,
-                              int skip_levels = 0) {
+// One octave's pyramid in steps: step -1 = workspace + resample from the frame, step i >= 0 =
+// Gaussian level i (blurred from level i-1, Sift.cpp:145-160).  The levels of one octave must be
+// enqueued in order on one stream; steps of different octaves may be interleaved by the host.
+static int octave_pyramid_step(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, const float* d_gray, int oi, int step) {
     const Plan& pl = ctx->plan;
     const OctavePlan& oc = pl.oct[oi];
     const size_t PX = (size_t)oc.W * oc.H;
     const int pyWidth = pl.prm.intvls + 3;
-    int rc;
-    if ((rc = ensure(ctx, ws.base, PX * 4))) return rc;
-    if ((rc = ensure(ctx, ws.tmp, PX * 4))) return rc;
-    if ((rc = ensure(ctx, ws.gau_all, PX * 4 * pyWidth))) return rc;
-    float* base = (float*)ws.base.p;
-    float* tmp = (float*)ws.tmp.p;
+    if (step < 0) {
+        int rc;
+        if ((rc = ensure(ctx, ws.base, PX * 4))) return rc;
+        if ((rc = ensure(ctx, ws.tmp, PX * 4))) return rc;
+        if ((rc = ensure(ctx, ws.gau_all, PX * 4 * pyWidth))) return rc;
+        launch_first(ctx, st, d_gray, pl.w, pl.h, oc.curr_size, (float*)ws.base.p, oc.W, oc.H);
+        return SIFT_HIP_OK;
+    }
     float* gau = (float*)ws.gau_all.p;
-    const float* taps = (const float*)ctx->table.p;
-    launch_first(ctx, st, d_gray, pl.w, pl.h, oc.curr_size, base, oc.W, oc.H);
-    for (int i = 0; i < pyWidth - skip_levels; i++) {
-        const float* src = (i == 0) ? base : gau + (size_t)(i - 1) * PX;
-        launch_blur(ctx, st, src, tmp, gau + (size_t)i * PX, oc.W, oc.H, taps + oc.tap_off[i], oc.tap_len[i],
-                    pl.prm.blur_mode);
+    const float* src = (step == 0) ? (const float*)ws.base.p : gau + (size_t)(step - 1) * PX;
+    launch_blur(ctx, st, src, (float*)ws.tmp.p, gau + (size_t)step * PX, oc.W, oc.H,
+                (const float*)ctx->table.p + oc.tap_off[step], oc.tap_len[step], pl.prm.blur_mode);
+    return SIFT_HIP_OK;
+}
+
+static int run_octave_pyramid(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, const float* d_gray, int oi,
+                              int skip_levels = 0) {
+    const int pyWidth = ctx->plan.prm.intvls + 3;
+    for (int step = -1; step < pyWidth - skip_levels; step++) {
+        const int rc = octave_pyramid_step(ctx, ws, st, d_gray, oi, step);
+        if (rc) return rc;
     }
     return SIFT_HIP_OK;
 }
@@ -321,7 +331,8 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     const bool serial = ctx->profiling || ctx->force_serial || noct < 2;
     auto stream_of = [&](int oi) -> hipStream_t {
         if (serial || oi == 0) return ctx->stream;
-        return (oi == 1 || ctx->n_side < 2) ? ctx->side_stream : ctx->side_stream2;
+        if (oi == 1 || ctx->n_side < 2) return ctx->side_stream;
+        return oi < 4 ? ctx->side_stream2 : ctx->side_stream3;
     };
     if (frame_state == 1 && !serial) hipEventRecord(ctx->ev_start, ctx->stream);
     ctx->side_busy = !serial;
@@ -369,6 +380,52 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         }
         return r;
     };
+    static const bool interleave = [] { const char* e = std::getenv("SIFT_HIP_INTERLEAVE"); return !e || e[0] != '0'; }();
+    if (interleave && !serial && ctx->n_side >= 2 && noct > 2) {
+        // Three streams: the pyramids of octaves 0-2 are enqueued level by level in turn, so that
+        // all three streams have work within the first few launches instead of after octave 0's
+        // whole pyramid (the host needs ~5 us per launch; the small octaves' long, few-pixel kernels
+        // are what ends the frame, so they should start first, not 0.2 ms in).
+        // the first octave of each stream: 0, 1, 2 and (frames with more than four octaves) 4
+        int heads[4] = {0, 1, 2, 4};
+        const int nhead = noct > 4 ? 4 : 3;
+        int nlev[4];
+        for (int k = 0; k < nhead; k++) {
+            const int oi = heads[k];
+            OctWs& ws = ctx->lanes[oi];
+            ws.stream = stream_of(oi);
+            const int top_K = pl.oct[oi].tap_len[prm.intvls + 2];
+            ws.lazy_top = !prm.subpixel && !ctx->full_top_level && top_K <= 1024;
+            nlev[k] = prm.intvls + 3 - (ws.lazy_top ? 1 : 0);
+        }
+        if ((rc = octave_pyramid_step(ctx, ctx->lanes[0], stream_of(0), d_gray, 0, -1))) return rc;
+        if ((rc = octave_pyramid_step(ctx, ctx->lanes[0], stream_of(0), d_gray, 0, 0))) return rc;
+        if (frame_state == 1 && !hip_ok(ctx, hipEventSynchronize(ctx->ev_start), "frame upload")) return SIFT_HIP_ERR_HIP;
+        for (int k = nhead - 1; k >= 1; k--)
+            if ((rc = octave_pyramid_step(ctx, ctx->lanes[heads[k]], stream_of(heads[k]), d_gray, heads[k], -1))) return rc;
+        for (int lvl = 0; lvl < prm.intvls + 3; lvl++)
+            for (int k = nhead - 1; k >= 0; k--)
+                if (lvl < nlev[k] && !(k == 0 && lvl == 0) &&
+                    (rc = octave_pyramid_step(ctx, ctx->lanes[heads[k]], stream_of(heads[k]), d_gray, heads[k], lvl)))
+                    return rc;
+        for (int k = nhead - 1; k >= 0; k--)
+            if ((rc = enqueue_part(heads[k], 1))) return rc;
+        // the followers on the two deep streams (octave 3; octaves 5, 6, ...) in turn
+        int a = 3, b = 5;
+        while (a < 4 || b < noct) {
+            if (a < 4 && a < noct) {
+                if ((rc = enqueue_part(a, 0))) return rc;
+                if ((rc = enqueue_part(a, 1))) return rc;
+            }
+            a = 4;
+            if (b < noct) {
+                if ((rc = enqueue_part(b, 0))) return rc;
+                if ((rc = enqueue_part(b, 1))) return rc;
+                b++;
+            }
+        }
+        return check_async(ctx, "extract launch");
+    }
     if ((rc = enqueue_part(0, 0))) return rc;
     // the main stream has its first long kernels; now the frame must be there for the side stream
     if (frame_state == 1 && !serial && !hip_ok(ctx, hipEventSynchronize(ctx->ev_start), "frame upload"))
@@ -424,7 +481,8 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
             }
         }
         if (!hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)") ||
-            !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream2), "extract (second side stream)"))
+            !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream2), "extract (second side stream)") ||
+            !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream3), "extract (third side stream)"))
             return SIFT_HIP_ERR_HIP;
     }
     if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
@@ -561,6 +619,7 @@ static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Fetche
         if (ctx->side_busy) {
             hipEventRecord(ctx->ev_side[f & 1], ctx->side_stream);
             hipEventRecord(ctx->ev_side2[f & 1], ctx->side_stream2);
+            hipEventRecord(ctx->ev_side3[f & 1], ctx->side_stream3);
         }
         if (f >= 1) {
             swap_output_sets(ctx);  // look at frame f-1's set
@@ -568,7 +627,8 @@ static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Fetche
             // meanwhile), then copies on the copy stream: no stream ever waits for another.
             if (!hip_ok(ctx, hipEventSynchronize(ctx->ev_frame[(f - 1) & 1]), "batch frame") ||
                 (ctx->side_busy && (!hip_ok(ctx, hipEventSynchronize(ctx->ev_side[(f - 1) & 1]), "batch frame (side)") ||
-                                    !hip_ok(ctx, hipEventSynchronize(ctx->ev_side2[(f - 1) & 1]), "batch frame (side 2)"))))
+                                    !hip_ok(ctx, hipEventSynchronize(ctx->ev_side2[(f - 1) & 1]), "batch frame (side 2)") ||
+                                    !hip_ok(ctx, hipEventSynchronize(ctx->ev_side3[(f - 1) & 1]), "batch frame (side 3)"))))
                 return SIFT_HIP_ERR_HIP;
             int overflow = 0;
             rc = fetch_features(ctx, out + (size_t)(f - 1) * cap, cap, &n[f - 1], nullptr, &overflow, ctx->copy_stream,
@@ -635,6 +695,8 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
             hipSuccess ||
         hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, ctx->side_priority == 0 ? 0 : prio_hi) !=
             hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->side_stream3, hipStreamNonBlocking, ctx->side_priority == 0 ? 0 : prio_hi) !=
+            hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_frame[0], hipEventDisableTiming) != hipSuccess ||
@@ -643,6 +705,8 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
         hipEventCreateWithFlags(&ctx->ev_side[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_side2[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_side2[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_side3[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_side3[1], hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counters, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&ctx->h_counters_alt, G_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         sift_hip_destroy(ctx);
@@ -662,6 +726,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
     if (ctx->side_stream2) hipStreamSynchronize(ctx->side_stream2);
+    if (ctx->side_stream3) hipStreamSynchronize(ctx->side_stream3);
     if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
     for (OctWs& ws : ctx->lanes) {
         DevBuf* wb[] = {&ws.base, &ws.tmp, &ws.gau_all, &ws.masks, &ws.row_cnt, &ws.row_off, &ws.cand, &ws.cand_mask,
@@ -685,11 +750,13 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_frame) if (e) hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_side) if (e) hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_side2) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_side3) if (e) hipEventDestroy(e);
     for (auto& e : ctx->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->free_events) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) hipStreamDestroy(ctx->side_stream2);
+    if (ctx->side_stream3) hipStreamDestroy(ctx->side_stream3);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
     return SIFT_HIP_OK;
@@ -842,6 +909,7 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
         hipStreamSynchronize(ctx->stream);
         hipStreamSynchronize(ctx->side_stream);
         hipStreamSynchronize(ctx->side_stream2);
+        hipStreamSynchronize(ctx->side_stream3);
         if (!hip_ok(ctx, hipMemcpy(slot[0], frames + (size_t)f * px, px * 4, hipMemcpyHostToDevice), "upload frame"))
             return nullptr;
         return slot[0];
@@ -851,6 +919,7 @@ int sift_hip_extract_batch(sift_hip_ctx* ctx, const float* frames, int w, int h,
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->side_stream);
     hipStreamSynchronize(ctx->side_stream2);
+    hipStreamSynchronize(ctx->side_stream3);
     for (int i = 0; i < 2; i++) hipEventDestroy(up[i]);
     return worst;
 }
@@ -1251,6 +1320,7 @@ int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset
     if (ctx->timeline && !ctx->events.empty()) {
         hipStreamSynchronize(ctx->side_stream);
         hipStreamSynchronize(ctx->side_stream2);
+        hipStreamSynchronize(ctx->side_stream3);
         // a frame starts at a "resample" group on the main stream; times are relative to the last one
         size_t first = 0;
         for (size_t i = 0; i < ctx->events.size(); i++)
@@ -1260,7 +1330,7 @@ int sift_hip_profile_read(sift_hip_ctx* ctx, float* ms, int* launches, int reset
             float t0 = 0.f, t1 = 0.f;
             hipEventElapsedTime(&t0, ctx->events[first].a, e.a);
             hipEventElapsedTime(&t1, ctx->events[first].a, e.b);
-            const int q = e.st == ctx->stream ? 0 : (e.st == ctx->side_stream ? 1 : 2);
+            const int q = e.st == ctx->stream ? 0 : (e.st == ctx->side_stream ? 1 : (e.st == ctx->side_stream2 ? 2 : 3));
             std::fprintf(stderr, "timeline q%d %*s%8.1f + %7.1f  %s\n", q, 4 * q, "", t0 * 1e3f, (t1 - t0) * 1e3f,
                          sift_hip_kernel_class_name(e.cls));
         }

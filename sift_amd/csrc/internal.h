@@ -83,7 +83,9 @@ struct sift_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // octave 1 of a frame (urgent priority); never waits on another stream
-    hipStream_t side_stream2 = nullptr;  // octaves >= 2: many short kernels that fill the gaps of the other two
+    hipStream_t side_stream2 = nullptr;  // octaves 2 and 3: many short kernels that fill the gaps of the other two
+    hipStream_t side_stream3 = nullptr;  // octaves >= 4 (frames processed with more than four octaves): a chain of
+                                         // long-kernel, few-pixel launches that would otherwise end the frame alone
     int n_side = 2;                      // side streams in use (SIFT_HIP_NSIDE = 1: octaves >= 1 all on side_stream)
     hipStream_t copy_stream = nullptr;
     bool side_busy = false;             // the last enqueue put work on side_stream
@@ -108,7 +110,8 @@ struct sift_hip_ctx {
     sifthip::DevBuf blend_ws, blend_l, blend_r;  // multiBandBlend: pyramids and scratch; device copies of host images
     hipEvent_t ev_frame[2] = {nullptr, nullptr};  // end of a batch frame's work on `stream` ...
     hipEvent_t ev_side[2] = {nullptr, nullptr};   // ... on `side_stream`
-    hipEvent_t ev_side2[2] = {nullptr, nullptr};  // ... and on `side_stream2`
+    hipEvent_t ev_side2[2] = {nullptr, nullptr};  // ... on `side_stream2`
+    hipEvent_t ev_side3[2] = {nullptr, nullptr};  // ... and on `side_stream3`
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
 

@@ -155,6 +155,57 @@ struct Window<double, P> {
     }
 };
 
+// K taps over P consecutive outputs in blocks of 16 taps: the 16+P-1 inputs of the NEXT block are
+// read (through rd(j) = input j of the run, j = 0 .. K+P-2; rd must tolerate j up to K+P+14) before
+// the current block is consumed, so that the read latency is paid once per 16 taps, not once per
+// tap as with a P-slot ring when P is small and few waves are resident.  Per output the products
+// are still added in ascending tap order.
+template <typename ACC, int P, typename RD>
+__device__ __forceinline__ void conv_blocked(RD rd, const float* __restrict__ taps, int K, ACC (&acc)[P]) {
+    constexpr int TB = 16, NV = TB + P - 1;
+#pragma unroll
+    for (int p = 0; p < P; p++) acc[p] = 0;
+    float v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) v[j] = rd(j);
+    int k = 0;
+    for (; k + TB <= K; k += TB) {
+        float vn[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) vn[j] = rd(k + TB + j);
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+            const float g = taps[k + t];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                if constexpr (sizeof(ACC) == sizeof(double)) {
+                    const float prod = v[t + p] * g;
+                    acc[p] += (double)prod;
+                } else {
+                    acc[p] = fmaf(v[t + p], g, acc[p]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) v[j] = vn[j];
+    }
+#pragma unroll
+    for (int t = 0; t < TB; t++) {
+        if (k + t < K) {  // wave-uniform
+            const float g = taps[k + t];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                if constexpr (sizeof(ACC) == sizeof(double)) {
+                    const float prod = v[t + p] * g;
+                    acc[p] += (double)prod;
+                } else {
+                    acc[p] = fmaf(v[t + p], g, acc[p]);
+                }
+            }
+        }
+    }
+}
+
 // LDS index with one pad word per P so that lanes P floats apart hit distinct banks
 // (lane stride P+1 words, odd).
 template <int P>
@@ -196,27 +247,29 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
     const int base = lane * P;
     if (x0 + base >= W) return;
     ACC acc[P];
-    Window<ACC, P> win;
+    {
+        Window<ACC, P> win;
 #pragma unroll
-    for (int p = 0; p < P; p++) {
-        acc[p] = 0;
-        win.set(p, s[padx<P>(base + p)]);
-    }
-    int k = 0;
-    for (; k + P <= K; k += P) {
+        for (int p = 0; p < P; p++) {
+            acc[p] = 0;
+            win.set(p, s[padx<P>(base + p)]);
+        }
+        int k = 0;
+        for (; k + P <= K; k += P) {
+#pragma unroll
+            for (int u = 0; u < P; u++) {
+                const float g = taps[k + u];
+                win.step(acc, u, g);
+                win.set(u, s[padx<P>(base + k + u + P)]);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < P; u++) {
-            const float g = taps[k + u];
-            win.step(acc, u, g);
-            win.set(u, s[padx<P>(base + k + u + P)]);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < P; u++) {
-        if (k + u < K) {  // wave-uniform
-            const float g = taps[k + u];
-            win.step(acc, u, g);
-            win.set(u, s[padx<P>(base + k + u + P)]);
+            if (k + u < K) {  // wave-uniform
+                const float g = taps[k + u];
+                win.step(acc, u, g);
+                win.set(u, s[padx<P>(base + k + u + P)]);
+            }
         }
     }
     float* o = out + (size_t)y * W + x0 + base;
@@ -315,27 +368,29 @@ __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__
     for (int c = wave * P; c < TH; c += 4 * P) {
         if (y0 + c >= H) break;  // wave-uniform
         ACC acc[P];
-        Window<ACC, P> win;
+        {
+            Window<ACC, P> win;
 #pragma unroll
-        for (int p = 0; p < P; p++) {
-            acc[p] = 0;
-            win.set(p, s[(c + p) * 64 + lane]);
-        }
-        int k = 0;
-        for (; k + P <= K; k += P) {
+            for (int p = 0; p < P; p++) {
+                acc[p] = 0;
+                win.set(p, s[(c + p) * 64 + lane]);
+            }
+            int k = 0;
+            for (; k + P <= K; k += P) {
+#pragma unroll
+                for (int u = 0; u < P; u++) {
+                    const float g = taps[k + u];
+                    win.step(acc, u, g);
+                    win.set(u, s[(c + k + u + P) * 64 + lane]);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < P; u++) {
-                const float g = taps[k + u];
-                win.step(acc, u, g);
-                win.set(u, s[(c + k + u + P) * 64 + lane]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < P; u++) {
-            if (k + u < K) {
-                const float g = taps[k + u];
-                win.step(acc, u, g);
-                win.set(u, s[(c + k + u + P) * 64 + lane]);
+                if (k + u < K) {
+                    const float g = taps[k + u];
+                    win.step(acc, u, g);
+                    win.set(u, s[(c + k + u + P) * 64 + lane]);
+                }
             }
         }
         if (x < W) {
@@ -399,6 +454,52 @@ __global__ __launch_bounds__(256) void blur_col_global_kernel(const float* __res
     }
 }
 
+
+// Kernels longer than the image (deep octaves: a few thousand pixels under kernels of hundreds
+// to thousands of taps): most taps read a clamped index, so instead of staging K-1+n clamped
+// copies the whole row (column strip) goes to LDS once and the index is clamped on the LDS read.
+template <typename ACC, int P>
+__global__ __launch_bounds__(64) void blur_row_whole_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int W, int H, const float* __restrict__ taps, int K) {
+    extern __shared__ float s[];  // the W pixels of the row
+    const int lane = threadIdx.x;
+    const int r = K >> 1;
+    const int y = blockIdx.y;
+    const float* row = in + (size_t)y * W;
+    for (int i = lane; i < W; i += 64) s[i] = row[i];
+    __syncthreads();
+    const int xb = (blockIdx.x * 64 + lane) * P;
+    if (xb >= W) return;
+    auto rd = [&](int xx) -> float { return s[max(0, min(xx, W - 1))]; };
+    ACC acc[P];
+    conv_blocked<ACC, P>([&](int j) { return rd(xb - r + j); }, taps, K, acc);
+#pragma unroll
+    for (int p = 0; p < P; p++)
+        if (xb + p < W) out[(size_t)y * W + xb + p] = (float)acc[p];
+}
+
+template <typename ACC, int P>
+__global__ __launch_bounds__(256) void blur_col_whole_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int W, int H, const float* __restrict__ taps, int K) {
+    extern __shared__ float s[];  // all H rows of the workgroup's 64 columns
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = K >> 1;
+    const int x = blockIdx.x * 64 + lane;
+    const int xc = min(x, W - 1);
+    for (int i = wave; i < H; i += 4) s[i * 64 + lane] = in[(size_t)i * W + xc];
+    __syncthreads();
+    const int yb = (blockIdx.y * 4 + wave) * P;
+    if (yb >= H) return;
+    auto rd = [&](int yy) -> float { return s[max(0, min(yy, H - 1)) * 64 + lane]; };
+    ACC acc[P];
+    conv_blocked<ACC, P>([&](int j) { return rd(yb - r + j); }, taps, K, acc);
+    if (x < W) {
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            if (yb + p < H) out[(size_t)(yb + p) * W + x] = (float)acc[p];
+    }
+}
 
 // ---- exact column pass for short kernels: input-stationary ------------------------
 // The taps are symmetric bit for bit (g[k] == g[K-1-k]: the kernel is built from its
@@ -710,7 +811,10 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         const int n_in = 64 * P + K - 1 + P;
         const size_t lds = (size_t)(n_in + n_in / P + 1) * sizeof(float);
         dim3 grid((W + 64 * P - 1) / (64 * P), H);
-        if (lds <= (size_t)kMaxColLds)
+        if (W <= K && (size_t)W * sizeof(float) <= (size_t)kMaxColLds)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_whole_kernel<ACC, P>), grid, dim3(64), (size_t)W * sizeof(float), st,
+                               src, tmp, W, H, d_taps, K);
+        else if (lds <= (size_t)kMaxColLds)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_kernel<ACC, P>), grid, dim3(64), lds, st, src, tmp, W, H,
                                d_taps, K);
         else
@@ -721,6 +825,12 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
         if constexpr (sizeof(ACC) == sizeof(double)) {
             if (col_stream(st, tmp, dst, W, H, d_taps, K)) return;
+        }
+        if (H <= K && (size_t)H * 256 <= (size_t)kMaxColLds) {
+            dim3 grid((W + 63) / 64, (H + 4 * P - 1) / (4 * P));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_whole_kernel<ACC, P>), grid, dim3(256), (size_t)H * 256, st, tmp,
+                               dst, W, H, d_taps, K);
+            return;
         }
         // tile height: as tall as keeps the LDS tile modest (occupancy) for this K
         int TH = 16 * P;
