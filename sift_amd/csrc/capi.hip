@@ -381,7 +381,9 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         return r;
     };
     static const bool interleave = [] { const char* e = std::getenv("SIFT_HIP_INTERLEAVE"); return !e || e[0] != '0'; }();
-    if (interleave && !serial && ctx->n_side >= 2 && noct > 2) {
+    // (not in the batch pipeline, where the previous frame's tail keeps the device busy meanwhile and
+    // launching octave by octave measured 5 % faster)
+    if (interleave && !ctx->pipelined && !serial && ctx->n_side >= 2 && noct > 2) {
         // Three streams: the pyramids of octaves 0-2 are enqueued level by level in turn, so that
         // all three streams have work within the first few launches instead of after octave 0's
         // whole pyramid (the host needs ~5 us per launch; the small octaves' long, few-pixel kernels
@@ -610,7 +612,9 @@ static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Fetche
         n[f] = 0;
         const float* d = frame_ptr(f);
         swap_output_sets(ctx);  // frame f writes the set that frame f-2 has released
+        ctx->pipelined = true;
         rc = enqueue_extract(ctx, d, w, h, prm, cap, cand_cap, false, 0);
+        ctx->pipelined = false;
         if (rc) {
             hipStreamSynchronize(ctx->stream);
             return rc;

@@ -89,6 +89,7 @@ struct sift_hip_ctx {
     int n_side = 2;                      // side streams in use (SIFT_HIP_NSIDE = 1: octaves >= 1 all on side_stream)
     hipStream_t copy_stream = nullptr;
     bool side_busy = false;             // the last enqueue put work on side_stream
+    bool pipelined = false;             // inside the batch pipeline: the device never idles between frames
     std::string last_error;
 
     sifthip::Plan plan;
