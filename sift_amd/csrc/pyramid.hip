@@ -339,9 +339,17 @@ __global__ __launch_bounds__(256) void blur_col_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = K >> 1;
-    const int x = blockIdx.x * 64 + lane;
+    // Tiles that share halo rows are vertical neighbours.  Workgroup ids are dealt round-robin to
+    // the 8 XCDs (one L2 each): remapped so that one XCD owns a contiguous run of tiles in
+    // column-major order, the K-1 halo rows of a tile are L2 hits instead of fabric reads.
+    const int ntile = gridDim.x * gridDim.y;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = ntile >> 3, r8 = ntile & 7, xcd = bid & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tbx = lin / (int)gridDim.y, tby = lin - tbx * (int)gridDim.y;
+    const int x = tbx * 64 + lane;
     const int xc = min(x, W - 1);
-    const int y0 = blockIdx.y * TH;
+    const int y0 = tby * TH;
     const int rows_in = TH + K - 1;
     if (y0 - r >= 0 && y0 - r + rows_in <= H) {
         // interior tile: no clamping, four rows of loads in flight per wave
