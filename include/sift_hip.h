@@ -11,7 +11,7 @@
  *
  * Threading: a context is bound to one device and is not thread-safe.  Use one
  * context per GPU; distinct contexts may be driven concurrently from different
- * threads.  A context overlaps the octaves of a frame on two HIP streams of its own
+ * threads.  A context overlaps the octaves of a frame on several HIP streams of its own
  * and joins them on the host; no stream of the library ever waits on another
  * stream's event, so it cannot stall behind other users of the device's hardware
  * queues (further contexts, the caller's own streams, RCCL).
@@ -110,7 +110,7 @@ int sift_hip_extract(sift_hip_ctx* ctx, const float* img, int w, int h, int chan
                      const sift_hip_params* params, sift_hip_feat* out, int cap, int* n, float* hist);
 /* Same, with the image already in device memory (gray only); out/hist stay host.  The frame
  * must be complete, or be produced by work already enqueued on sift_hip_stream(ctx) (the call
- * then waits for that work on the host before it uses its second stream). */
+ * then waits for that work on the host before it uses its other streams). */
 int sift_hip_extract_dev(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
                          const sift_hip_params* params, sift_hip_feat* out, int cap, int* n, float* hist);
 /* nframes gray frames of equal size, contiguous on the host; frame f writes
