@@ -493,6 +493,19 @@ def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
     assert np.array_equal(bits(out), bits(sift.gau_blur(img, 1.6)))
 
 
+def test_kernel_longer_than_the_image_bit_exact(sift, oracle):
+    """Images shorter or narrower than the kernel go through the passes that stage the whole row /
+    column strip once and clamp on the LDS read: every outputs-per-thread variant (chosen by pixel
+    count), exact mode against the oracle, float mode within its tolerance."""
+    rng = np.random.default_rng(41)
+    for (h, w), p in (((20, 170000), 6.4), ((170000, 20), 6.4), ((30, 40000), 9.05), ((40000, 30), 9.05),
+                      ((24, 3000), 12.8), ((3000, 24), 12.8), ((7, 5), 25.6)):
+        img = rng.random((h, w), dtype=np.float32)
+        want = oracle.gau_blur(img, p)
+        assert np.array_equal(bits(sift.gau_blur(img, p)), bits(want)), (h, w, p)
+        assert np.max(np.abs(sift.gau_blur(img, p, blur_mode=1) - want)) < 2e-6, (h, w, p)
+
+
 def test_two_contexts_extract_concurrently(sift):
     """Two contexts on one device driven from two threads: each keeps its two streams (the
     library joins them on the host, no stream waits on another's event) and both give the
