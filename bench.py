@@ -341,6 +341,19 @@ def main():
         extras["warp_perspective_kernel_ms"] = round(ctx.profile_read()["warp"][0], 4)
         ctx.warp_cylinder(rgb, float(W))
         extras["warp_cylinder_kernel_ms"] = round(ctx.profile_read()["warp"][0], 4)
+        # multi-band blend of two frames of the workload's size whose overlap is a quarter of their width
+        # and all but 7 of their rows (multiBandBlend's dx, dy are the overlap's width and height; host
+        # images in and out; kernel time of the "blend" class and the host-to-host call)
+        left = rng.integers(1, 255, (H, W, 3)).astype(np.uint8)
+        right = rng.integers(1, 255, (H, W, 3)).astype(np.uint8)
+        ctx.multiband_blend(left.copy(), right.copy(), W // 4, H - 7)
+        ctx.profile_read()
+        l2, r2 = left.copy(), right.copy()
+        t0 = time.perf_counter()
+        ctx.multiband_blend(l2, r2, W // 4, H - 7)
+        extras["blend_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        extras["blend_kernels_ms"] = round(ctx.profile_read()["blend"][0], 4)
+        extras["blend_case"] = "two %dx%d RGB frames, overlap %d x %d" % (W, H, W // 4, H - 7)
         ctx.profile(False)
 
     # ---- the other single-GPU configurations of the baseline (rank 0, N = 1; not `value`) ----------

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void overlap_copy_kernel(const uint8_t* __rest
 // dr) are ordinary locals that keep their value from line to line -- and from the
 // column sweep to the row sweep -- when a line holds nothing but black.  Lines are
 // independent apart from that carry, so each sweep runs as: per-line search (parallel),
-// carry along the lines (one thread), per-line fill + second search (parallel), carry,
+// carry along the lines (a scan), per-line fill + second search (parallel), carry,
 // per-line fill (parallel).  A line is `len` samples `si` floats apart; lines are `so`
 // floats apart.
 __device__ __forceinline__ bool lit(const float* p) { return p[0] != 0.f || p[1] != 0.f || p[2] != 0.f; }
@@ -78,15 +78,37 @@ __global__ __launch_bounds__(64) void line_first_kernel(const float* __restrict_
 
 // found[l] >= 0 replaces the carried value, -1 keeps it; at_least: lower bound applied to the
 // carried value after every line (the reference's `dr = dr < 1 ? 1 : dr`), INT_MIN for none.
-__global__ void carry_kernel(int* __restrict__ found, int nlines, int* __restrict__ carried, int at_least) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    int v = *carried;
-    for (int l = 0; l < nlines; l++) {
-        if (found[l] >= 0) v = found[l];
+// One 256-thread workgroup: line l takes the value of the last line <= l that found something
+// (a max-scan over "position of the last hit"), or the value carried in, 256 lines per step.
+__global__ __launch_bounds__(256) void carry_kernel(int* __restrict__ found, int nlines, int* __restrict__ carried,
+                                                    int at_least) {
+    __shared__ int s_f[256];
+    __shared__ int s_wave[4];
+    __shared__ int s_prev;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_prev = *carried;
+    __syncthreads();
+    for (int base = 0; base < nlines; base += 256) {
+        const int l = base + tid;
+        const int f = l < nlines ? found[l] : -1;
+        s_f[tid] = f;
+        int pos = f >= 0 ? tid : -1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pos, o);
+            if (lane >= o) pos = max(pos, t);
+        }
+        if (lane == 63) s_wave[wave] = pos;
+        __syncthreads();
+        for (int w = 0; w < wave; w++) pos = max(pos, s_wave[w]);
+        int v = pos >= 0 ? s_f[pos] : s_prev;
         if (v < at_least) v = at_least;
-        found[l] = v;
+        if (l < nlines) found[l] = v;
+        __syncthreads();
+        if (l == min(base + 255, nlines - 1)) s_prev = v;
+        __syncthreads();
     }
-    *carried = v;
+    if (tid == 0) *carried = s_prev;
 }
 
 __global__ __launch_bounds__(64) void line_upfill_last_kernel(float* __restrict__ img, int nlines, int len, size_t so,
@@ -439,10 +461,10 @@ int run_multiband_blend(sift_hip_ctx* ctx, uint8_t* d_l, int lw, int lh, uint8_t
             const size_t so = sweep == 0 ? 3 : (size_t)3 * W, si = sweep == 0 ? (size_t)3 * W : 3;
             const dim3 g((nl + 63) / 64);
             hipLaunchKernelGGL(line_first_kernel, g, dim3(64), 0, st, (const float*)base.p, nl, len, so, si, d_idx);
-            hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(1), 0, st, d_idx, nl, d_carry + 0, INT32_MIN);
+            hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(256), 0, st, d_idx, nl, d_carry + 0, INT32_MIN);
             hipLaunchKernelGGL(line_upfill_last_kernel, g, dim3(64), 0, st, base.p, nl, len, so, si, (const int*)d_idx,
                                d_idx + nline + 8);
-            hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(1), 0, st, d_idx + nline + 8, nl, d_carry + 1, 1);
+            hipLaunchKernelGGL(carry_kernel, dim3(1), dim3(256), 0, st, d_idx + nline + 8, nl, d_carry + 1, 1);
             hipLaunchKernelGGL(line_downfill_kernel, g, dim3(64), 0, st, base.p, nl, len, so, si,
                                (const int*)(d_idx + nline + 8));
         }
