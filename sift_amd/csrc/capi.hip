@@ -278,8 +278,8 @@ static int check_async(sift_hip_ctx* ctx, const char* what) {
 // The whole of Sift::pyramid for one device-resident gray frame; results stay on
 // the device (per-octave feature buffers, ctx->gcounters).  No device-side
 // synchronisation between streams anywhere: octave 0 runs on ctx->stream, the
-// other octaves on ctx->side_stream, every kernel depends only on its
-// predecessors in its own stream, and the host joins the two (wait_extract).  A
+// other octaves on the side streams, every kernel depends only on its
+// predecessors in its own stream, and the host joins them (fetch_features).  A
 // stream that waits on another stream's event parks a barrier packet in its
 // hardware queue; streams share the few hardware queues of a process, so such a
 // packet can sit in front of the very work that has to signal it -- the library
@@ -287,7 +287,7 @@ static int check_async(sift_hip_ctx* ctx, const char* what) {
 // torch, RCCL).
 // frame_state: 0 = the frame is complete in device memory, 1 = it is produced by
 // work already enqueued on ctx->stream (an upload, the gray conversion): the host
-// then waits for that work before it feeds the side stream.
+// then waits for that work before it feeds the side streams.
 static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params& prm,
                            int feat_cap, int cand_cap, bool want_hist, int frame_state) {
     int rc = build_plan(ctx, w, h, prm);
@@ -336,11 +336,8 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     };
     if (frame_state == 1 && !serial) hipEventRecord(ctx->ev_start, ctx->stream);
     ctx->side_busy = !serial;
-    // Host launch order: octave 0's pyramid first (long kernels that keep the main stream busy),
-    // then all of octave 1 so that the side stream starts early, then the rest of octave 0,
-    // then the remaining octaves (within run-to-run noise of launching octave by octave on
-    // this host, but it does not depend on the host launching faster than octave 0 runs).
-    // Each octave's own launches stay in order on its stream.
+    // An octave's launches stay in order on its stream; the host's order between octaves is chosen
+    // below (level by level in turn for a single frame, octave by octave inside the batch pipeline).
     auto enqueue_part = [&](int oi, int part) -> int {  // part 0 = pyramid, 1 = detect ... describe
         OctWs& ws = ctx->lanes[oi];
         const hipStream_t st = stream_of(oi);
@@ -429,7 +426,7 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         return check_async(ctx, "extract launch");
     }
     if ((rc = enqueue_part(0, 0))) return rc;
-    // the main stream has its first long kernels; now the frame must be there for the side stream
+    // the main stream has its first long kernels; now the frame must be there for the side streams
     if (frame_state == 1 && !serial && !hip_ok(ctx, hipEventSynchronize(ctx->ev_start), "frame upload"))
         return SIFT_HIP_ERR_HIP;
     if (noct > 1) {
@@ -452,7 +449,7 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     return check_async(ctx, "extract launch");
 }
 
-// Waits (on the host) for the frame's work on the side stream, copies the counters
+// Waits (on the host) for the frame's work on the side streams, copies the counters
 // back, then each octave's features (and histograms) to their place in the caller's
 // array: octave-major, as the reference appends them.  *cand_overflow receives the
 // largest candidate count that did not fit the table (0 if all did).  A caller that
