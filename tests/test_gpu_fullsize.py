@@ -98,6 +98,27 @@ def test_1080p_octave0_features_equal_oracle(sift, oracle):
     compare_records(f, h, fo, ho)
 
 
+def test_720p_reference_octave_count_features_equal_oracle(sift, oracle):
+    # octaves = 0 -> the reference's own count (Sift.cpp:131-139): the deep octaves are a few thousand
+    # pixels under kernels longer than the image (whole-row / whole-column passes, their last level
+    # built as an image because it has more than 1024 taps) and run on a stream of their own;
+    # every record of every octave against the oracle.
+    from scipy import ndimage
+
+    # fine blobs plus the same kind of field magnified 8x and 40x, so that deep octaves find something
+    img = 0.5 * sift_amd.blob_image(1280, 720, seed=23)
+    img += 0.25 * ndimage.zoom(sift_amd.blob_image(160, 90, seed=24), 8, order=1)
+    img += 0.25 * ndimage.zoom(sift_amd.blob_image(32, 18, seed=25), 40, order=1)
+    img = np.ascontiguousarray(img.astype(np.float32))
+    noct = sift_amd.pyramid_octaves(1280, 720)
+    assert noct >= 6
+    f, h = sift.extract(img, SiftParams(octaves=0), cap=1 << 16, want_hist=True)
+    fo, ho = oracle.extract(img, octaves=noct)
+    print("octaves %d, features per octave size:" % noct, {float(v): int((fo["size"] == v).sum()) for v in np.unique(fo["size"])})
+    assert len(fo) > 1500 and len(np.unique(fo["size"])) >= 4
+    compare_records(f, h, fo, ho)
+
+
 def test_4k_octave1_features_equal_oracle_on_a_crop(sift, oracle, frame4k):
     # Octave 1 resamples 1:1 (exactly, for widths below 4097), every later stage is
     # local: blur radii of its six levels sum to 163 px, the descriptor window adds
