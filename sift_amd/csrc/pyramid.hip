@@ -879,7 +879,9 @@ template <typename ACC>
 static void launch_blur_t(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                           const float* d_taps, int K) {
     // outputs per thread: fewer for small octaves, which otherwise cannot fill 1024 SIMDs
-    if ((size_t)W * H < (size_t)1 << 20)
+    // (measured on 960 x 540, five levels of 79...309 taps: 4 outputs per thread 191 us against 195 with 2 in
+    // exact arithmetic, 127 against 150 in float arithmetic)
+    if ((size_t)W * H < (size_t)1 << 18)
         launch_blur_tp<ACC, 2>(ctx, st, src, tmp, dst, W, H, d_taps, K);
     else if ((size_t)W * H < (size_t)3 << 20)
         launch_blur_tp<ACC, 4>(ctx, st, src, tmp, dst, W, H, d_taps, K);
