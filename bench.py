@@ -354,6 +354,19 @@ def main():
         extras["blend_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         extras["blend_kernels_ms"] = round(ctx.profile_read()["blend"][0], 4)
         extras["blend_case"] = "two %dx%d RGB frames, overlap %d x %d" % (W, H, W // 4, H - 7)
+        # blen2img's pixel work for the same pair in one device call (projections, blend, canvas; two images
+        # up, the canvas down) next to the same work as separate host-to-host calls
+        ft, dxp, bdy = float(W), W // 4, H - 7
+        top0, left1, top1, pc, pr = H // 10, W - dxp, H // 10 + 7, (W - dxp) + W, 7 + H + 150
+        ctx.panorama_pair(left, right, ft, dxp, bdy, top0, left1, top1, pc, pr)
+        t0 = time.perf_counter()
+        ctx.panorama_pair(left, right, ft, dxp, bdy, top0, left1, top1, pc, pr)
+        extras["panorama_pair_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        t0 = time.perf_counter()
+        c1, _, _ = ctx.warp_cylinder(left, ft)
+        c2, _, _ = ctx.warp_cylinder(right, ft)
+        ctx.multiband_blend(c1, c2, dxp, bdy)
+        extras["panorama_separate_calls_ms"] = round((time.perf_counter() - t0) * 1e3, 3)  # (canvas loops on the host not included)
         ctx.profile(False)
 
     # ---- the other single-GPU configurations of the baseline (rank 0, N = 1; not `value`) ----------

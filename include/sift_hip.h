@@ -274,6 +274,18 @@ int sift_hip_multiband_blend(sift_hip_ctx* ctx, uint8_t* l_rgb, int lw, int lh, 
 int sift_hip_multiband_blend_dev(sift_hip_ctx* ctx, uint8_t* d_l_rgb, int lw, int lh, uint8_t* d_r_rgb, int rw, int rh,
                                  int dx, int dy);
 
+/* ---- the pixel work of blen2img in one call: replaces the sequence warping (Sift/stitch/Blend.cpp:974),
+ * multiBandBlend (:994-996) and the canvas assembly (:1010-1031) for one pair of images.  Both
+ * images (interleaved 8-bit RGB, host memory) are projected onto the cylinder of focal length
+ * `focal`, the dx x |blend_dy| overlap is blended (the arguments multiBandBlend gets), and the
+ * cols x rows canvas (host memory, every pixel written) receives the first projection top0 rows
+ * down from its top-left corner and the non-black pixels of the second at column left1, row top1;
+ * what falls outside the canvas is dropped.  Only the two images cross to the device and only
+ * the canvas comes back.  Results equal the three separate calls followed by the host loop. */
+int sift_hip_panorama_pair(sift_hip_ctx* ctx, const uint8_t* img1_rgb, int w1, int h1, const uint8_t* img2_rgb, int w2,
+                           int h2, float focal, int dx, int blend_dy, int top0, int left1, int top1, uint8_t* canvas_rgb,
+                           int cols, int rows);
+
 /* ---- measurement ------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the
  * context's stream; totals are kept per kernel class. */

@@ -130,6 +130,8 @@ def load_library() -> C.CDLL:
         "sift_hip_warp_cylinder_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
         "sift_hip_multiband_blend": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "sift_hip_multiband_blend_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sift_hip_panorama_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
         "sift_hip_kernel_class_name": (C.c_char_p, [C.c_int]),
@@ -402,6 +404,17 @@ class SiftHip:
             assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3 and a.flags.c_contiguous
         self._check(self.lib.sift_hip_multiband_blend(self.h, _ptr(l_rgb), l_rgb.shape[1], l_rgb.shape[0], _ptr(r_rgb),
                                                       r_rgb.shape[1], r_rgb.shape[0], dx, dy))
+
+    def panorama_pair(self, img1: np.ndarray, img2: np.ndarray, focal: float, dx: int, blend_dy: int, top0: int, left1: int,
+                      top1: int, cols: int, rows: int) -> np.ndarray:
+        """blen2img's pixel work (stitch/Blend.cpp:974-1031) in one call: cylinder projections, blend, canvas."""
+        for a in (img1, img2):
+            assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3 and a.flags.c_contiguous
+        canvas = np.empty((rows, cols, 3), np.uint8)
+        self._check(self.lib.sift_hip_panorama_pair(self.h, _ptr(img1), img1.shape[1], img1.shape[0], _ptr(img2), img2.shape[1],
+                                                    img2.shape[0], focal, dx, blend_dy, top0, left1, top1, _ptr(canvas), cols,
+                                                    rows))
+        return canvas
 
     # ---- measurement ----------------------------------------------------------------
     def profile(self, enable: bool):

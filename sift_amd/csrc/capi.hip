@@ -740,7 +740,8 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all,
                       &ctx->ransac.blk, &ctx->ransac.pairs, &ctx->ransac.src, &ctx->ransac.flags, &ctx->ransac.samples,
                       &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best,
-                      &ctx->warp_src, &ctx->warp_dst, &ctx->warp_edges, &ctx->blend_ws, &ctx->blend_l, &ctx->blend_r};
+                      &ctx->warp_src, &ctx->warp_dst, &ctx->warp_edges, &ctx->blend_ws, &ctx->blend_l, &ctx->blend_r,
+                      &ctx->pano_src, &ctx->pano_canvas};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
@@ -1254,6 +1255,38 @@ int sift_hip_multiband_blend(sift_hip_ctx* ctx, uint8_t* l_rgb, int lw, int lh, 
     hipMemcpyAsync(r_rgb, ctx->blend_r.p, rb, hipMemcpyDeviceToHost, ctx->stream);
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "multiband_blend")) return SIFT_HIP_ERR_HIP;
     return check_async(ctx, "multiband_blend");
+}
+
+int sift_hip_panorama_pair(sift_hip_ctx* ctx, const uint8_t* img1_rgb, int w1, int h1, const uint8_t* img2_rgb, int w2,
+                           int h2, float focal, int dx, int blend_dy, int top0, int left1, int top1, uint8_t* canvas_rgb,
+                           int cols, int rows) {
+    if (bad_ctx(ctx) || !img1_rgb || !img2_rgb || !canvas_rgb || !(focal > 0.f) || blend_args_bad(w1, h1, w2, h2, dx, blend_dy) ||
+        warp_size_bad(cols, rows))
+        return SIFT_HIP_ERR_ARG;
+    const size_t b1 = (size_t)w1 * h1 * 3, b2 = (size_t)w2 * h2 * 3, bc = (size_t)cols * rows * 3;
+    int rc;
+    if ((rc = ensure(ctx, ctx->pano_src, b1 + b2))) return rc;
+    if ((rc = ensure(ctx, ctx->blend_l, b1))) return rc;
+    if ((rc = ensure(ctx, ctx->blend_r, b2))) return rc;
+    if ((rc = ensure(ctx, ctx->pano_canvas, bc))) return rc;
+    uint8_t* d_src1 = (uint8_t*)ctx->pano_src.p;
+    uint8_t* d_src2 = d_src1 + b1;
+    hipStream_t st = ctx->stream;
+    if (!hip_ok(ctx, hipMemcpyAsync(d_src1, img1_rgb, b1, hipMemcpyHostToDevice, st), "upload image 1") ||
+        !hip_ok(ctx, hipMemcpyAsync(d_src2, img2_rgb, b2, hipMemcpyHostToDevice, st), "upload image 2"))
+        return SIFT_HIP_ERR_HIP;
+    // warping (Blend.cpp:974): both projections stay on the device
+    launch_warp_cylinder(ctx, st, d_src1, w1, h1, focal, (uint8_t*)ctx->blend_l.p, nullptr, nullptr);
+    launch_warp_cylinder(ctx, st, d_src2, w2, h2, focal, (uint8_t*)ctx->blend_r.p, nullptr, nullptr);
+    // multiBandBlend (Blend.cpp:994-996) on the projections, then the canvas (Blend.cpp:1010-1031)
+    rc = sift_hip_multiband_blend_dev(ctx, (uint8_t*)ctx->blend_l.p, w1, h1, (uint8_t*)ctx->blend_r.p, w2, h2, dx, blend_dy);
+    if (rc) return rc;
+    launch_compose_pair(ctx, st, (const uint8_t*)ctx->blend_l.p, w1, h1, (const uint8_t*)ctx->blend_r.p, w2, h2, top0, left1,
+                        top1, (uint8_t*)ctx->pano_canvas.p, cols, rows);
+    if (!hip_ok(ctx, hipMemcpyAsync(canvas_rgb, ctx->pano_canvas.p, bc, hipMemcpyDeviceToHost, st), "download canvas") ||
+        !hip_ok(ctx, hipStreamSynchronize(st), "panorama_pair"))
+        return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "panorama_pair");
 }
 
 static int ransac_args_bad(sift_hip_ctx* ctx, const void* q, int nq, const void* r, int nr, const void* best, int m,

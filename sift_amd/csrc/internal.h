@@ -108,6 +108,7 @@ struct sift_hip_ctx {
     unsigned char* match_scratch = nullptr;  // this device's copy of the matcher's static work area (not owned)
     sifthip::RansacWs ransac;
     sifthip::DevBuf warp_src, warp_dst, warp_edges;
+    sifthip::DevBuf pano_src, pano_canvas;       // sift_hip_panorama_pair: the two uploaded images; the canvas
     sifthip::DevBuf blend_ws, blend_l, blend_r;  // multiBandBlend: pyramids and scratch; device copies of host images
     hipEvent_t ev_frame[2] = {nullptr, nullptr};  // end of a batch frame's work on `stream` ...
     hipEvent_t ev_side[2] = {nullptr, nullptr};   // ... on `side_stream`
@@ -190,6 +191,8 @@ void launch_warp_cylinder(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_sr
                           uint8_t* d_out, float* d_upedge, float* d_downedge);
 // blend.hip: multiBandBlend on two device-resident 8-bit RGB images, updated in place
 int run_multiband_blend(sift_hip_ctx* ctx, uint8_t* d_l, int lw, int lh, uint8_t* d_r, int rw, int rh, int dx, int dy);
+void launch_compose_pair(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_a, int ca, int ra, const uint8_t* d_b, int cb,
+                         int rb, int top0, int left1, int top1, uint8_t* d_canvas, int cols, int rows);
 // ransac.hip; features and best in device memory, outputs in host memory
 int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_hip_feat* d_r, int nr,
                const int32_t* d_best, int m, float p_badxform, float err_tol, unsigned seed, float* H9,

@@ -154,4 +154,46 @@ void launch_warp_cylinder(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_sr
                                                        reinterpret_cast<float2*>(d_downedge));
 }
 
+// ---- canvas assembly of blen2img (Blend.cpp:1010-1031) ---------------------------------
+// The black canvas receives the first image top0 rows down from its top-left corner, then the
+// non-black pixels of the second image at (left1, top1); pixels that fall outside the canvas
+// are dropped.  One thread per canvas pixel.
+__global__ __launch_bounds__(256) void compose_pair_kernel(const uint8_t* __restrict__ a, int ca, int ra,
+                                                           const uint8_t* __restrict__ b, int cb, int rb, int top0,
+                                                           int left1, int top1, uint8_t* __restrict__ canvas, int cols,
+                                                           int rows) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)cols * rows) return;
+    const int y = (int)(e / cols), x = (int)(e - (size_t)y * cols);
+    uint8_t v0 = 0, v1 = 0, v2 = 0;
+    const int ya = y - top0;
+    if (ya >= 0 && ya < ra && x < ca) {
+        const uint8_t* s = a + ((size_t)ya * ca + x) * 3;
+        v0 = s[0];
+        v1 = s[1];
+        v2 = s[2];
+    }
+    const int yb = y - top1, xb = x - left1;
+    if (yb >= 0 && yb < rb && xb >= 0 && xb < cb) {
+        const uint8_t* s = b + ((size_t)yb * cb + xb) * 3;
+        if (s[0] != 0 || s[1] != 0 || s[2] != 0) {
+            v0 = s[0];
+            v1 = s[1];
+            v2 = s[2];
+        }
+    }
+    uint8_t* d = canvas + e * 3;
+    d[0] = v0;
+    d[1] = v1;
+    d[2] = v2;
+}
+
+void launch_compose_pair(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_a, int ca, int ra, const uint8_t* d_b, int cb,
+                         int rb, int top0, int left1, int top1, uint8_t* d_canvas, int cols, int rows) {
+    ProfScope ps(ctx, SIFT_HIP_K_WARP, st);
+    const size_t n = (size_t)cols * rows;
+    compose_pair_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_a, ca, ra, d_b, cb, rb, top0, left1, top1,
+                                                                               d_canvas, cols, rows);
+}
+
 }  // namespace sifthip

@@ -124,39 +124,30 @@ void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::ve
     if (!RANSAC_feat || RANSAC_num < 2) throw std::runtime_error("blen2img: needs at least two consensus matches");
     const std::vector<Raw> input = {to_raw(img1), to_raw(img2)};
     const float ft = getFocal(HomogMat, img1.size(), img2.size());
-    std::vector<fpoint> upedge, downedge;
-    std::vector<Raw> cyl;
-    warping(input, ft, cyl, upedge, downedge);
     int dx = 0, dy = 0;
     align_offsets(input[0], input[1], RANSAC_feat, RANSAC_num, ft, &dx, &dy);
-    const int r0 = cyl[0].getRow(), c0 = cyl[0].getCol(), r1 = cyl[1].getRow(), c1 = cyl[1].getCol();
+    // the cylindrical projections keep the size of their images (stitch.cpp:129-131)
+    const int r0 = input[0].getRow(), c0 = input[0].getCol(), r1 = input[1].getRow(), c1 = input[1].getCol();
     // an offset beyond the image height means the second image lies above the first (Blend.cpp:999-1003)
     const bool above = dy > r0;
-    multiBandBlend(cyl[0], cyl[1], dx, above ? -(r0 - std::abs(r0 - dy)) : dy);
+    const int blend_dy = above ? -(r0 - std::abs(r0 - dy)) : dy;
     // canvas: the first image a tenth of its height down, the second dx columns into its right
     // edge and shifted by the row offset; 150 spare rows (Blend.cpp:1010-1031)
     const int cols = (c0 - dx) + c1;
     const int rows2 = (above ? 0 : r0 - dy) + r1 + 150;
     if (cols <= 0 || rows2 <= 0) throw std::runtime_error("blen2img: the alignment leaves no canvas");
-    std::vector<unsigned char> canvas((size_t)cols * rows2 * 3);
     const int top0 = r0 / 10;
-    for (int y = 0; y < r0; y++) {
-        const int row = y + top0;
-        if (row < 0 || row >= rows2) continue;
-        const int n = std::min(c0, cols);
-        std::copy_n(&cyl[0].RGB[(size_t)y * c0 * 3], (size_t)n * 3, &canvas[(size_t)row * cols * 3]);
-    }
     const int left1 = c0 - dx;
     const int top1 = above ? top0 - std::abs(r0 - dy) : top0 + std::abs(r0 - dy);
-    for (int y = 0; y < r1; y++) {
-        const int row = y + top1;
-        if (row < 0 || row >= rows2) continue;  // (the reference's buffer has no such guard; its canvas is only tall enough for images of up to 1500 rows)
-        for (int x = 0; x < c1; x++) {
-            const int col = x + left1;
-            if (col < 0 || col >= cols) continue;
-            const unsigned char* s = &cyl[1].RGB[((size_t)y * c1 + x) * 3];
-            if (s[0] != 0 || s[1] != 0 || s[2] != 0) std::copy_n(s, 3, &canvas[((size_t)row * cols + col) * 3]);
-        }
+    // warping (Blend.cpp:974), multiBandBlend (:994-996) and the canvas loops (:1010-1031; rows and
+    // columns that leave the canvas are dropped, where the reference's buffer, tall enough for
+    // images of up to 1500 rows only, has no guard) in one device call: two images up, the canvas down
+    std::vector<unsigned char> canvas((size_t)cols * rows2 * 3);
+    {
+        sift_amd::ContextUse use;
+        check(use.ctx, sift_hip_panorama_pair(use.ctx, input[0].RGB.data(), c0, r0, input[1].RGB.data(), c1, r1, ft, dx, blend_dy,
+                                              top0, left1, top1, canvas.data(), cols, rows2),
+              "sift_hip_panorama_pair");
     }
     dst = ImgRaw(canvas, (uint32_t)cols, (uint32_t)rows2, 24);
 }
