@@ -1265,12 +1265,13 @@ int sift_hip_panorama_pair(sift_hip_ctx* ctx, const uint8_t* img1_rgb, int w1, i
         return SIFT_HIP_ERR_ARG;
     const size_t b1 = (size_t)w1 * h1 * 3, b2 = (size_t)w2 * h2 * 3, bc = (size_t)cols * rows * 3;
     int rc;
-    if ((rc = ensure(ctx, ctx->pano_src, b1 + b2))) return rc;
+    const size_t off2 = (b1 + 255) / 256 * 256;  // the second image starts on an aligned address of the shared buffer
+    if ((rc = ensure(ctx, ctx->pano_src, off2 + b2))) return rc;
     if ((rc = ensure(ctx, ctx->blend_l, b1))) return rc;
     if ((rc = ensure(ctx, ctx->blend_r, b2))) return rc;
     if ((rc = ensure(ctx, ctx->pano_canvas, bc))) return rc;
     uint8_t* d_src1 = (uint8_t*)ctx->pano_src.p;
-    uint8_t* d_src2 = d_src1 + b1;
+    uint8_t* d_src2 = d_src1 + off2;
     hipStream_t st = ctx->stream;
     if (!hip_ok(ctx, hipMemcpyAsync(d_src1, img1_rgb, b1, hipMemcpyHostToDevice, st), "upload image 1") ||
         !hip_ok(ctx, hipMemcpyAsync(d_src2, img2_rgb, b2, hipMemcpyHostToDevice, st), "upload image 2"))
