@@ -8,6 +8,7 @@
 // stdout: one JSON line with counts, the RANSAC homography (image 2 -> image 1)
 //          and the indices of its consensus features in image 2
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,13 +55,26 @@ int main(int argc, char** argv) {
     fclose(f);
     try {
         ImgRaw img1(a, w, h, (uint16_t)(8 * ch)), img2(b, w, h, (uint16_t)(8 * ch));
+        {   // warm-up (context creation, workspace growth), so that the times below are steady-state
+            Sift warm(img1);
+            warm.pyramid();
+        }
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point t1) {
+            return std::chrono::duration<double, std::milli>(t1 - t0).count();
+        };
+        const auto t0 = now();
         Sift fea1(img1);
         fea1.pyramid();
         Sift fea2(img2);
         fea2.pyramid();
+        const auto t1 = now();
         Stitching match(fea1, fea2);
         sift_amd::ransac_seed() = 1234;  // reproducible sample stream for the checker
+        const auto t2 = now();
         match.Check(th);
+        const auto t3 = now();
+        const double ms_pyramids = ms(t0, t1), ms_check = ms(t2, t3);
         // Check() ran RANSAC on the GPU; the CPU implementation must agree bit for bit
         Feature** cpu_in = nullptr;
         int cpu_n = 0;
@@ -151,7 +165,8 @@ int main(int argc, char** argv) {
             fwrite(match.Panorama.raw_img.data(), 4, match.Panorama.raw_img.size(), pf);
             fclose(pf);
         }
-        printf("{\"threads_equal\": %s, \"pano\": [%u, %u], \"focal\": %.9g, ", threads_equal ? "true" : "false",
+        printf("{\"ms_two_pyramids\": %.3f, \"ms_check\": %.3f, ", ms_pyramids, ms_check);
+        printf("\"threads_equal\": %s, \"pano\": [%u, %u], \"focal\": %.9g, ", threads_equal ? "true" : "false",
                match.Panorama.width, match.Panorama.height,
                match.HomogMat.size() == 9 ? getFocal(match.HomogMat, img1.size(), img2.size()) : 0.f);
         printf("\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
