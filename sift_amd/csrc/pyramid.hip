@@ -155,14 +155,14 @@ struct Window<double, P> {
     }
 };
 
-// K taps over P consecutive outputs in blocks of 16 taps: the 16+P-1 inputs of the NEXT block are
-// read (through rd(j) = input j of the run, j = 0 .. K+P-2; rd must tolerate j up to K+P+14) before
-// the current block is consumed, so that the read latency is paid once per 16 taps, not once per
+// K taps over P consecutive outputs in blocks of TB taps: the TB+P-1 inputs of the NEXT block are
+// read (through rd(j) = input j of the run, j = 0 .. K+P-2; rd must tolerate j up to K+P+TB-2) before
+// the current block is consumed, so that the read latency is paid once per TB taps, not once per
 // tap as with a P-slot ring when P is small and few waves are resident.  Per output the products
 // are still added in ascending tap order.
-template <typename ACC, int P, typename RD>
+template <typename ACC, int P, int TB = 16, typename RD>
 __device__ __forceinline__ void conv_blocked(RD rd, const float* __restrict__ taps, int K, ACC (&acc)[P]) {
-    constexpr int TB = 16, NV = TB + P - 1;
+    constexpr int NV = TB + P - 1;
 #pragma unroll
     for (int p = 0; p < P; p++) acc[p] = 0;
     float v[NV];
@@ -509,6 +509,127 @@ __global__ __launch_bounds__(256) void blur_col_whole_kernel(const float* __rest
     }
 }
 
+// Images of a few thousand pixels under kernels of hundreds to thousands of taps (the deepest
+// octaves): there are too few outputs to fill the chip whatever the mapping, so the time of a pass
+// is the length of one output's chain of K ordered additions.  One output per thread keeps that
+// chain as short as the arithmetic allows: per tap one product, one conversion, one addition, and
+// reads that need no index arithmetic in the loop.
+//   row pass: the run of 64 outputs plus its K-1 neighbours is staged with clamped indices once;
+//             lane l then reads staged[l + j] (an immediate offset per tap);
+//   column pass: a wave owns one output row, so the clamped source row of every tap is the same
+//             for all lanes (scalar arithmetic) and the whole 64-column strip sits in LDS.
+// One output per thread, inputs and taps both read a block of TB ahead (rd(j) = input j, tp(k) =
+// tap k; both must tolerate indices up to K + 2*TB - 1): nothing in the loop waits for memory, so
+// a pass takes the K ordered additions of its outputs and little more.
+template <typename ACC, int TB, typename RD, typename TP>
+__device__ __forceinline__ ACC conv_chain(RD rd, TP tp, int K, ACC acc = 0) {
+    float va[TB], ga[TB], vb[TB], gb[TB];  // two blocks in turn: one is consumed while the other is fetched
+    auto fetch = [&](float (&v)[TB], float (&g)[TB], int k) {
+#pragma unroll
+        for (int j = 0; j < TB; j++) {
+            v[j] = rd(k + j);
+            g[j] = tp(k + j);
+        }
+    };
+    auto consume = [&](const float (&v)[TB], const float (&g)[TB], int n) {  // n = TB: the whole block
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+            if (t < n) {  // wave-uniform
+                if constexpr (sizeof(ACC) == sizeof(double)) {
+                    const float prod = v[t] * g[t];
+                    acc += (double)prod;
+                } else {
+                    acc = fmaf(v[t], g[t], acc);
+                }
+            }
+        }
+    };
+    fetch(va, ga, 0);
+    int k = 0;
+    for (; k + 2 * TB <= K; k += 2 * TB) {
+        fetch(vb, gb, k + TB);
+        consume(va, ga, TB);
+        fetch(va, ga, k + 2 * TB);
+        consume(vb, gb, TB);
+    }
+    if (k + TB <= K) {
+        fetch(vb, gb, k + TB);
+        consume(va, ga, TB);
+        consume(vb, gb, K - k - TB);
+    } else {
+        consume(va, ga, K - k);
+    }
+    return acc;
+}
+
+template <typename ACC>
+__global__ __launch_bounds__(64) void blur_row_tiny_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
+                                                           int H, const float* __restrict__ taps, int K) {
+    extern __shared__ float s[];  // the K taps (+ 64 of read-ahead slack), then the staged inputs of the middle run
+    const int lane = threadIdx.x;
+    const int r = K >> 1;
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * 64;
+    const int xmax = min(x0 + 63, W - 1);
+    const float* row = in + (size_t)y * W;
+    // Output x reads column x + k - r at tap k, clamped: for the 64 outputs of this wave the first `a`
+    // taps all read column 0 and the taps from `c` on all read column W-1 (for these octaves nearly all
+    // of them); only the run between them fetches staged inputs.  Same products, same order.
+    const int a = min(max(r - xmax + 1, 0), K), c = min(max(W - 1 - x0 + r, a), K);
+    float* s_taps = s;
+    float* s_in = s + K + 64;
+    for (int i = lane; i < K + 64; i += 64) s_taps[i] = i < K ? taps[i] : 0.f;
+    const int n_in = (c - a) + 64 + 64;  // lane l reads staged[l + j], j < (c - a) + 64 with the read-ahead
+    for (int i0 = lane; i0 < n_in; i0 += 64 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = row[max(0, min(x0 + a + i0 + 64 * u - r, W - 1))];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 64 * u < n_in) s_in[i0 + 64 * u] = t[u];
+    }
+    const float left = row[0], right = row[W - 1];
+    __syncthreads();
+    ACC acc = conv_chain<ACC, 32>([&](int) { return left; }, [&](int k) { return s_taps[k]; }, a);
+    acc = conv_chain<ACC, 32>([&](int j) { return s_in[lane + j]; }, [&](int k) { return s_taps[a + k]; }, c - a, acc);
+    acc = conv_chain<ACC, 32>([&](int) { return right; }, [&](int k) { return s_taps[c + k]; }, K - c, acc);
+    if (x0 + lane < W) out[(size_t)y * W + x0 + lane] = (float)acc;
+}
+
+template <typename ACC>
+__global__ __launch_bounds__(256) void blur_col_tiny_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int W, int H, const float* __restrict__ taps, int K) {
+    extern __shared__ float s[];  // all H rows of the workgroup's 64 columns, then the K taps (+ 64)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = K >> 1;
+    const int x = blockIdx.x * 64 + lane;
+    const int xc = min(x, W - 1);
+    for (int i0 = wave; i0 < H; i0 += 4 * 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = in[(size_t)min(i0 + 4 * u, H - 1) * W + xc];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 4 * u < H) s[(i0 + 4 * u) * 64 + lane] = t[u];
+    }
+    float* s_taps = s + (size_t)H * 64;
+    for (int i = threadIdx.x; i < K + 64; i += 256) s_taps[i] = i < K ? taps[i] : 0.f;
+    __syncthreads();
+    const int yb = blockIdx.y * 4 + wave;  // this wave's output row
+    if (yb >= H) return;
+    // Tap k reads row yb - r + k, clamped: the first `a` taps all read row 0 and the taps from `c` on
+    // all read row H-1 (for these octaves that is nearly all of them), so those two runs multiply one
+    // value by successive taps and only the short middle run fetches rows.  Same products, same order.
+    const int a = min(max(r - yb + 1, 0), K), c = min(max(r - yb + H - 1, a), K);
+    const float top = s[lane], bot = s[(H - 1) * 64 + lane];
+    ACC acc = conv_chain<ACC, 32>([&](int) { return top; }, [&](int k) { return s_taps[k]; }, a);
+    acc = conv_chain<ACC, 32>([&](int j) { return s[min(yb - r + a + j, H - 1) * 64 + lane]; },
+                              [&](int k) { return s_taps[a + k]; }, c - a, acc);
+    acc = conv_chain<ACC, 32>([&](int) { return bot; }, [&](int k) { return s_taps[c + k]; }, K - c, acc);
+    if (x < W) out[(size_t)yb * W + x] = (float)acc;
+}
+
 // ---- exact column pass for short kernels: input-stationary ------------------------
 // The taps are symmetric bit for bit (g[k] == g[K-1-k]: the kernel is built from its
 // centre outwards), so the float product of an input with tap m serves two outputs,
@@ -819,7 +940,13 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         const int n_in = 64 * P + K - 1 + P;
         const size_t lds = (size_t)(n_in + n_in / P + 1) * sizeof(float);
         dim3 grid((W + 64 * P - 1) / (64 * P), H);
-        if (W <= K && (size_t)W * sizeof(float) <= (size_t)kMaxColLds)
+        const bool tiny = (size_t)W * H < ((size_t)1 << 16);  // the deepest octaves: one output per thread
+        // (LDS: K + 64 taps; the middle run is at most min(K, W + 62) taps long, plus 128 of slack)
+        const size_t tiny_lds = (size_t)(K + 64 + std::min(K, W + 62) + 128) * sizeof(float);
+        if (tiny && tiny_lds <= (size_t)kMaxColLds)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_tiny_kernel<ACC>), dim3((W + 63) / 64, H), dim3(64), tiny_lds, st, src,
+                               tmp, W, H, d_taps, K);
+        else if (W <= K && (size_t)W * sizeof(float) <= (size_t)kMaxColLds)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_row_whole_kernel<ACC, P>), grid, dim3(64), (size_t)W * sizeof(float), st,
                                src, tmp, W, H, d_taps, K);
         else if (lds <= (size_t)kMaxColLds)
@@ -833,6 +960,11 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
         ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
         if constexpr (sizeof(ACC) == sizeof(double)) {
             if (col_stream(st, tmp, dst, W, H, d_taps, K)) return;
+        }
+        if ((size_t)W * H < ((size_t)1 << 16) && (size_t)H * 256 + (size_t)(K + 64) * sizeof(float) <= (size_t)kMaxColLds) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_tiny_kernel<ACC>), dim3((W + 63) / 64, (H + 3) / 4), dim3(256),
+                               (size_t)H * 256 + (size_t)(K + 64) * sizeof(float), st, tmp, dst, W, H, d_taps, K);
+            return;
         }
         if (H <= K && (size_t)H * 256 <= (size_t)kMaxColLds) {
             dim3 grid((W + 63) / 64, (H + 4 * P - 1) / (4 * P));
