@@ -499,7 +499,10 @@ def test_kernel_longer_than_the_image_bit_exact(sift, oracle):
     count), exact mode against the oracle, float mode within its tolerance."""
     rng = np.random.default_rng(41)
     for (h, w), p in (((20, 170000), 6.4), ((170000, 20), 6.4), ((30, 40000), 9.05), ((40000, 30), 9.05),
-                      ((24, 3000), 12.8), ((3000, 24), 12.8), ((7, 5), 25.6)):
+                      ((24, 3000), 12.8), ((3000, 24), 12.8), ((7, 5), 25.6),
+                      # the last octaves of a 4K frame: one output per thread, clamped runs of taps
+                      ((34, 60), 579.26), ((68, 120), 289.63), ((135, 240), 144.82), ((135, 240), 25.6), ((1, 200), 40.0),
+                      ((200, 1), 40.0), ((100, 130), 3.2)):
         img = rng.random((h, w), dtype=np.float32)
         want = oracle.gau_blur(img, p)
         assert np.array_equal(bits(sift.gau_blur(img, p)), bits(want)), (h, w, p)
