@@ -652,15 +652,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// Rows fetched ahead of their use: a ring of L registers with L a divisor of K (slot = step mod L
+// stays a compile-time constant in a body of K steps), long enough to cover the memory latency.
 template <int K>
-__global__ __launch_bounds__(64) void blur_col_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
+struct StreamGeom {
+    static constexpr int L = K == 55 ? 11 : K == 39 ? 13 : K == 21 ? 7 : K;
+    static constexpr int WAVES = K <= 11 ? 8 : K <= 21 ? 5 : K <= 39 ? 3 : 2;  // waves a SIMD is to hold (bounds the register count)
+};
+
+template <int K>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(StreamGeom<K>::WAVES, 8))) void blur_col_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             int W, int H, const float* __restrict__ taps, int seg) {
-    constexpr int R = K / 2;
+    constexpr int R = K / 2, L = StreamGeom<K>::L;
     const int lane = threadIdx.x;
     const int x = blockIdx.x * 64 + lane;
     const int xc = min(x, W - 1);  // lanes past the edge redo the last column and store nothing
     const int y0 = blockIdx.y * seg;
     const int y1 = min(y0 + seg, H);
+    const int nb = (y1 - y0 + K - 1) / K;  // the segment as blocks of K output rows (the last one may hang over y1)
     float g[R + 1];
 #pragma unroll
     for (int m = 0; m <= R; m++) g[m] = taps[m];
@@ -683,74 +692,108 @@ __global__ __launch_bounds__(64) void blur_col_stream_kernel(const float* __rest
     // rows above the image clamp to row 0, rows below it to row H-1: both are ends of the resource
     // whenever the clamp can apply (yb == 0 resp. yb + rows_in == H)
     int in_off = (y0 - R - yb) * row_bytes;  // offset of the next input row to fetch
-    auto load_next = [&]() -> float {
+    auto load_next = [&]() __attribute__((always_inline)) -> float {
         const int off = max(0, min(in_off, last_in));
         in_off += row_bytes;
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff, off, 0));
     };
-    // byte offset of the output the next step completes, per lane; starts 2R rows above the segment
-    // (negative = far beyond the resource as an unsigned offset) and advances one row per step
-    unsigned st_off = (x < W ? (unsigned)voff : 0x80000000u) + (unsigned)(-2 * R * row_bytes);
-    float cur[K], nxt[K];
+    unsigned st_off = x < W ? (unsigned)voff : 0x80000000u;  // byte offset of the next output row to complete
+    float cur[L];  // input row of step s sits in cur[s mod L]
 #pragma unroll
-    for (int t = 0; t < K; t++) cur[t] = load_next();
+    for (int t = 0; t < L; t++) cur[t] = load_next();
+    // Step s takes input row y0 - R + s and adds q[R-|d|] to output row y0 - R + s + d for d = dlo..dhi;
+    // the accumulator of output row o is slot (o - y0) mod K.  A full step (d = -R..R) completes output
+    // row y0 - 2R + s.  The first K-1 steps of a segment only feed rows of the segment (d >= R - s) and
+    // the last K-1 only rows above its end, so a segment costs exactly its own additions: segments can
+    // be short, which is what lets every SIMD hold its share of waves.
     // The float products of a step are formed one step ahead (a conversion issued right
     // behind the multiply that feeds it would stall the wave for the multiply's latency,
-    // and so would an addition right behind its conversion); each step runs
-    // conversions -> next step's products -> additions, in that order.
+    // and so would an addition right behind its conversion); each step runs conversions of the
+    // outer taps -> their additions -> conversions of the inner taps -> next step's products ->
+    // additions of the inner taps.
     constexpr int NP = (R + 2) / 2;  // packed multiplies per input
     float_pair pr[NP];
-    auto products = [&](float xv) {
+    auto products = [&](float xv, int mhi) __attribute__((always_inline)) {  // taps 0..mhi
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            const float_pair gp = {g[2 * i], (2 * i + 1 <= R) ? g[2 * i + 1] : 0.f};
-            pr[i] = gp * xv;  // one packed multiply, each half rounded to float as xv * g[m] is
+            if (2 * i <= mhi) {
+                const float_pair gp = {g[2 * i], (2 * i + 1 <= R) ? g[2 * i + 1] : 0.f};
+                pr[i] = gp * xv;  // one packed multiply, each half rounded to float as xv * g[m] is
+            }
         }
     };
-    products(cur[0]);
-    for (int iv0 = y0 - R; iv0 - R < y1; iv0 += K) {  // body: input rows iv0 .. iv0+K-1; slot of output row o is (o - (y0 - R)) mod K
+    // t = s mod K; mhi / next_mhi = highest tap index this / the next step uses (-1: no next step)
+    auto step = [&](int t, int dlo, int dhi, bool completes, int mhi, int next_mhi, bool refill) __attribute__((always_inline)) {
+        // in two halves (outer taps, then inner taps), so that only half of the converted products are live
+        constexpr int H1 = R / 2;
+        double q[R + 1];
 #pragma unroll
-        for (int t = 0; t < K; t++) nxt[t] = load_next();
+        for (int m = 0; m <= H1; m++)
+            if (m <= mhi) q[m] = (double)((m & 1) ? pr[m >> 1].y : pr[m >> 1].x);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < K; t++) {
-            double q[R + 1];
+        for (int d = -R; d <= R; d++)
+            if (d >= dlo && d <= dhi && R - (d < 0 ? -d : d) <= H1) acc[(t + d + R + 1) % K] += q[R - (d < 0 ? -d : d)];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m <= R; m++) q[m] = (double)((m & 1) ? pr[m >> 1].y : pr[m >> 1].x);
-            __builtin_amdgcn_sched_barrier(0);
-            products(t + 1 < K ? cur[t + 1] : nxt[0]);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int m = H1 + 1; m <= R; m++)
+            if (m <= mhi) q[m] = (double)((m & 1) ? pr[m >> 1].y : pr[m >> 1].x);
+        __builtin_amdgcn_sched_barrier(0);
+        if (next_mhi >= 0) products(cur[(t + 1) % L], next_mhi);
+        if (refill) cur[(t + 1) % L] = load_next();  // the row of step s + 1 + L
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int d = -R; d <= R; d++) acc[(t + d + K) % K] += q[R - (d < 0 ? -d : d)];
-            constexpr int kSlotBase = K - R;
-            const int slot = (t + kSlotBase) % K;  // output row iv0 + t - R is complete
+        for (int d = -R; d <= R; d++)
+            if (d >= dlo && d <= dhi && R - (d < 0 ? -d : d) > H1) acc[(t + d + R + 1) % K] += q[R - (d < 0 ? -d : d)];
+        if (completes) {
+            const int slot = (t + 1) % K;  // output row y0 - 2R + s
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[slot]), rout, (int)st_off, 0, 0);
             st_off += (unsigned)row_bytes;
             acc[slot] = 0.0;
-            // Pin every accumulator here: left alone the compiler moves additions and
-            // conversions across steps and keeps hundreds of converted products alive.
-#pragma unroll
-            for (int j = 0; j < K; j++) asm volatile("" : "+v"(acc[j]));
-            __builtin_amdgcn_sched_barrier(0);
         }
+        // Pin every accumulator here: left alone the compiler moves additions and
+        // conversions across steps and keeps hundreds of converted products alive.
 #pragma unroll
-        for (int t = 0; t < K; t++) cur[t] = nxt[t];
+        for (int j = 0; j < K; j++) asm volatile("" : "+v"(acc[j]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    products(cur[0], 0);
+    cur[0] = load_next();  // the row of step L
+    // lead-in: steps 0 .. K-2
+#pragma unroll
+    for (int t = 0; t < K - 1; t++)
+        step(t, R - t > -R ? R - t : -R, R, false, t < R ? t : R, t + 1 < R ? t + 1 : R, true);
+    // full steps K-1 .. nb*K - 2, a body of K at a time
+    for (int b = 1; b < nb; b++) {
+#pragma unroll
+        for (int u = 0; u < K; u++) step((K - 1 + u) % K, -R, R, true, R, R, true);
     }
+    // the last full step, then the K-1 steps that finish the rows still open
+    step(K - 1, -R, R, true, R, R, L <= K - 2);
+#pragma unroll
+    for (int j = 0; j < K - 1; j++)
+        step(j, -R, R - 1 - j, true, 2 * R - 1 - j < R ? 2 * R - 1 - j : R,
+             j + 1 < K - 1 ? (2 * R - 2 - j < R ? 2 * R - 2 - j : R) : -1, j + 1 + L <= K - 2);
 }
 
-// Segment length of the streaming column pass: one round of waves (as many as the
-// kernel's register count lets a SIMD hold), so that none waits for a free slot while
-// others finish, and segments long enough to keep the K-1 rows of lead-in cheap.
-static int stream_segment(int W, int H, int K) {
-    if (const char* e = std::getenv("SIFT_BLUR_SEG")) return std::max(1, std::atoi(e));
-    const int cols = (W + 63) / 64;
-    const int waves_per_simd = K <= 11 ? 6 : K <= 21 ? 4 : 2;
-    const int nseg = std::max(1, 1024 * waves_per_simd / cols);
-    return std::min(H, std::max((H + nseg - 1) / nseg, 2 * K));
+// Segment length of the streaming column pass, in whole blocks of K rows.  A SIMD issues for its
+// oldest wave first and fills the gaps with the others, so waves on one SIMD finish one after the
+// other and the pass takes as long as the fullest SIMD: the segments are cut so that the waves
+// come to about one full set of resident waves, rather a little less than a little more.
+template <int K>
+static int stream_segment(int W, int H) {
+    if (const char* e = std::getenv("SIFT_BLUR_SEG")) return (std::max(1, std::atoi(e)) + K - 1) / K * K;
+    const long cols = (W + 63) / 64;
+    const long slots = 1024L * StreamGeom<K>::WAVES;
+    auto waves = [&](long m) { return cols * ((H + m * K - 1) / (m * K)); };
+    long m = std::max(1L, (long)H * cols / (slots * K));
+    if (waves(m) > slots && waves(m + 1) * 100 >= slots * 85) m++;
+    return (int)(m * K);
 }
 
 template <int K>
 static void launch_col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps) {
-    const int seg = stream_segment(W, H, K);
+    const int seg = stream_segment<K>(W, H);
     dim3 grid((W + 63) / 64, (H + seg - 1) / seg);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_stream_kernel<K>), grid, dim3(64), 0, st, tmp, dst, W, H, d_taps, seg);
 }
@@ -759,9 +802,9 @@ static void launch_col_stream(hipStream_t st, const float* tmp, float* dst, int 
 static bool col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps, int K) {
     if (const char* e = std::getenv("SIFT_BLUR_STREAM")) {
         if (e[0] == '0') return false;
-    } else if ((size_t)W * H < ((size_t)16 << 20)) {
-        // smaller images give too few waves once the segments are long enough to pay for their
-        // lead-in (measured on 3840x2160: slower than the tiled pass at every segment length)
+    } else if ((size_t)((W + 63) / 64) * ((H + K - 1) / K) < 2048) {
+        // even the shortest segments give fewer than two waves per SIMD: the tiled pass spreads better
+        // (measured on 1920 x 1080: 39 taps 14 us tiled, 13-18 streaming; 55 taps 17 against 30)
         return false;
     }
     switch (K) {
@@ -770,6 +813,7 @@ static bool col_stream(hipStream_t st, const float* tmp, float* dst, int W, int 
         case 21: launch_col_stream<21>(st, tmp, dst, W, H, d_taps); return true;
         case 29: launch_col_stream<29>(st, tmp, dst, W, H, d_taps); return true;
         case 39: launch_col_stream<39>(st, tmp, dst, W, H, d_taps); return true;
+        case 55: launch_col_stream<55>(st, tmp, dst, W, H, d_taps); return true;
         default: return false;
     }
 }

@@ -441,7 +441,7 @@ def test_streaming_column_pass_bit_exact_on_ragged_shapes(sift, oracle, monkeypa
     monkeypatch.setenv("SIFT_BLUR_STREAM", "1")
     rng = np.random.default_rng(31)
     shapes = [(200, 131), (64, 300), (1, 77), (130, 1), (65, 40), (333, 95)]
-    for p, K in ((1.6, 11), (2.2627418, 15), (3.2, 21), (4.5254836, 29), (6.4, 39)):
+    for p, K in ((1.6, 11), (2.2627418, 15), (3.2, 21), (4.5254836, 29), (6.4, 39), (9.0509672, 55)):
         assert len(oracle.gau_matrix(p)) == K
         for i, (w, h) in enumerate(shapes):
             img = rng.random((h, w), dtype=np.float32)
