@@ -792,10 +792,16 @@ static int stream_segment(int W, int H) {
 }
 
 template <int K>
-static void launch_col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps) {
-    const int seg = stream_segment<K>(W, H);
+static bool launch_col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps) {
+    int seg = stream_segment<K>(W, H);
+    // the kernel addresses the rows of a segment with 32-bit byte offsets: very wide images get shorter segments
+    const long max_rows = (((long)1 << 31) - 1) / ((long)W * 4) - K;
+    if (max_rows < K) return false;
+    if (seg > max_rows) seg = (int)(max_rows / K * K);
     dim3 grid((W + 63) / 64, (H + seg - 1) / seg);
+    if (grid.y > 65535) return false;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_stream_kernel<K>), grid, dim3(64), 0, st, tmp, dst, W, H, d_taps, seg);
+    return true;
 }
 
 // true if a streaming kernel exists for this tap count (the pyramid's own short kernels)
@@ -808,12 +814,12 @@ static bool col_stream(hipStream_t st, const float* tmp, float* dst, int W, int 
         return false;
     }
     switch (K) {
-        case 11: launch_col_stream<11>(st, tmp, dst, W, H, d_taps); return true;
-        case 15: launch_col_stream<15>(st, tmp, dst, W, H, d_taps); return true;
-        case 21: launch_col_stream<21>(st, tmp, dst, W, H, d_taps); return true;
-        case 29: launch_col_stream<29>(st, tmp, dst, W, H, d_taps); return true;
-        case 39: launch_col_stream<39>(st, tmp, dst, W, H, d_taps); return true;
-        case 55: launch_col_stream<55>(st, tmp, dst, W, H, d_taps); return true;
+        case 11: return launch_col_stream<11>(st, tmp, dst, W, H, d_taps);
+        case 15: return launch_col_stream<15>(st, tmp, dst, W, H, d_taps);
+        case 21: return launch_col_stream<21>(st, tmp, dst, W, H, d_taps);
+        case 29: return launch_col_stream<29>(st, tmp, dst, W, H, d_taps);
+        case 39: return launch_col_stream<39>(st, tmp, dst, W, H, d_taps);
+        case 55: return launch_col_stream<55>(st, tmp, dst, W, H, d_taps);
         default: return false;
     }
 }
