@@ -60,6 +60,99 @@ __device__ __forceinline__ bool is_keypoint(const float* d, float v, float rad, 
     return val < thre;
 }
 
+// Neighbouring lanes' values (DPP wavefront shifts).
+__device__ __forceinline__ float from_lane_below(float v) {  // lane i receives lane i-1 (lane 0: unspecified)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float v) {  // lane i receives lane i+1 (lane 63: unspecified)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// The tests of four consecutive tile rows (ry0 .. ry0+3) by one wave, three scales per octave.
+// Reading the 27 neighbours of every pixel and layer from LDS is what bounded the kernel (its LDS
+// pipe was busy longer than its loads take); here every staged value is read once: the wave walks
+// down the six rows involved, lane = column, the left and right neighbours come from the adjacent
+// lanes (lanes 0 and 63 read the halo column), and the 3 x 3 x 3 maximum is built from per-row
+// 3-maxima kept in registers: per DoG layer max3(left, centre, right) of a row, max3 over the three
+// rows, max3 over the three layers.  The values and neighbours of the tested layers stay in
+// registers for the edge test.  Same comparisons and the same edge arithmetic as is_keypoint.
+template <int NLAY>
+__device__ __forceinline__ void detect_four_rows(const float* s_dog, int ry0, int lane, int x, int y0, int W, int H, int tx,
+                                                 int WW, const LayerConsts* __restrict__ lc, float thr,
+                                                 unsigned long long* __restrict__ masks, int* __restrict__ row_cnt) {
+    constexpr int LS = DET_LH * DET_LW;
+    constexpr bool lazy = NLAY == 4;
+    int rad[3];
+#pragma unroll
+    for (int l = 0; l < 3; l++) rad[l] = lc[l].radius;
+    float C[3][3], L[3][3], R[3][3];        // tested layers: value, left, right of the last three rows
+    float hmax[NLAY][3], hmin[NLAY][3];     // per layer and row: max / min of (left, centre, right)
+    const int hcol = lane == 0 ? 0 : DET_LW - 1;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {  // LDS row ry0 + i; slot = i mod 3
+        const int s = i % 3;
+        const float* row = s_dog + (ry0 + i) * DET_LW;
+#pragma unroll
+        for (int k = 0; k < NLAY; k++) {
+            const float d = row[k * LS + lane + 1];
+            const float hd = row[k * LS + hcol];
+            float l = from_lane_below(d), r = from_lane_above(d);
+            l = lane == 0 ? hd : l;
+            r = lane == 63 ? hd : r;
+            hmax[k][s] = fmaxf(fmaxf(l, d), r);
+            hmin[k][s] = fminf(fminf(l, d), r);
+            if (k >= 1 && k <= 3) {
+                C[k - 1][s] = d;
+                L[k - 1][s] = l;
+                R[k - 1][s] = r;
+            }
+        }
+        if (i < 2) continue;
+        const int y = y0 + ry0 + i - 2;  // centre row: LDS row ry0 + i - 1
+        if (y >= H) break;               // wave-uniform
+        const int sc = (s + 2) % 3, su = (s + 1) % 3, sd = s;  // centre, row above, row below
+        float vmax[NLAY], vmin[NLAY];
+#pragma unroll
+        for (int k = 0; k < NLAY; k++) {
+            vmax[k] = fmaxf(fmaxf(hmax[k][0], hmax[k][1]), hmax[k][2]);
+            vmin[k] = fminf(fminf(hmin[k][0], hmin[k][1]), hmin[k][2]);
+        }
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            const float v = C[l][sc];
+            const int rd = rad[l];
+            // scan bounds of Sift.cpp:178-179: r+1 <= y < H-r-1, r+1 <= x < W-r-1
+            bool hit = (H >= 2 * rd + 3) && (W >= 2 * rd + 3) && y >= rd + 1 && y < H - rd - 1 && x >= rd + 1 &&
+                       x < W - rd - 1 && (fabsf(v) > thr);
+            // layers l, l+1 (the tested one), l+2; the last is left out when it does not exist
+            float mx = fmaxf(vmax[l], vmax[l + 1]), mn = fminf(vmin[l], vmin[l + 1]);
+            if (!(lazy && l == 2)) {
+                mx = fmaxf(mx, vmax[l + 2 < NLAY ? l + 2 : l]);
+                mn = fminf(mn, vmin[l + 2 < NLAY ? l + 2 : l]);
+            }
+            if (hit) hit = !(v > 0.f ? (mx > v) : (mn < v));
+            if (hit) {
+                // harris_corner (Sift.cpp:105-129) with the reference's argument, the histogram radius
+                const float rf = (float)rd;
+                const float thre = ((rf + 1.f) * (rf + 1.f)) / rf;
+                const float Dxx = 2.f * v - L[l][sc] - R[l][sc];
+                const float Dyy = 2.f * v - C[l][su] - C[l][sd];
+                float Dxy = R[l][sd] + L[l][su] - R[l][su] - L[l][sd];
+                Dxy /= 4.f;
+                const float Tr = Dxx + Dyy;
+                const float Det = Dxx * Dyy - Dxy * Dxy;
+                const float val = (Tr * Tr / Det);
+                hit = val < thre;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) {
+                masks[((size_t)l * H + y) * WW + tx] = m;
+                if (m) atomicAdd(&row_cnt[l * H + y], __popcll(m));
+            }
+        }
+    }
+}
+
 // grid = (ceil(W/64), ceil(H/DET_TR)).  Writes every mask word of its tile (zeros
 // included) and adds the per-(layer,row) counts into row_cnt (zeroed beforehand).
 // NLAY = number of DoG layers staged when known at compile time, else 0.  With
@@ -141,6 +234,12 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restric
     }
     __syncthreads();
     const int x = x0 + lane;
+    if (NLAY > 0 && intvls == 3) {
+        static_assert(DET_TR == 16, "four waves of four rows");
+        if (y0 + 4 * wave < H)
+            detect_four_rows<(NLAY > 0 ? NLAY : 4)>(s_dog, 4 * wave, lane, x, y0, W, H, tx, WW, lc, thr, masks, row_cnt);
+        return;
+    }
     for (int ry = wave; ry < DET_TR; ry += 4) {
         const int y = y0 + ry;
         if (y >= H) break;  // wave-uniform
