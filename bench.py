@@ -305,12 +305,17 @@ def main():
         if args.blur_mode == 0:
             # fp32-FMA blur: not the reference's arithmetic (a fraction of a percent of keypoints change)
             fast = SiftParams(octaves=args.octaves, blur_mode=1)
-            nfast = ctx.extract_dev(d_frame, W, H, fast, out)
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(3):
                 nfast = ctx.extract_dev(d_frame, W, H, fast, out)
-            extras["blur_mode_1_ms_per_frame"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+            ctx.synchronize()
+            best = None
+            for _ in range(3):  # best of three groups of five: one slow call would otherwise move the figure by a third
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    nfast = ctx.extract_dev(d_frame, W, H, fast, out)
+                dt = (time.perf_counter() - t0) / 5
+                best = dt if best is None else min(best, dt)
+            extras["blur_mode_1_ms_per_frame"] = round(best * 1e3, 3)
             extras["blur_mode_1_features"] = int(nfast)
             ctx.extract_dev(d_frame, W, H, prm, out)  # back to the exact plan
         # the consumers behind the matcher: RANSAC homography over planted matches (host pointers in,
