@@ -461,6 +461,24 @@ def test_streaming_column_pass_bit_exact_on_ragged_shapes(sift, oracle, monkeypa
     assert np.array_equal(bits(sift.gau_blur(img, 3.2)), bits(oracle.gau_blur(img, 3.2)))
 
 
+def test_streaming_column_pass_on_a_very_wide_image(sift, monkeypatch):
+    """Rows of 2 MB: the segment the streaming column pass would choose (3198 rows) spans more than 2^31
+    bytes, which its 32-bit row offsets cannot address, so it must cut shorter segments (975 rows here,
+    two per column).  Checked bit for bit against the tiled column pass, which the other tests pin to
+    the oracle."""
+    w, h = 1 << 19, 1200
+    rng = np.random.default_rng(41)
+    img = np.tile(rng.random((h, 4096), dtype=np.float32), (1, w // 4096))
+    img[:, ::4099] = 0.0
+    monkeypatch.setenv("SIFT_BLUR_STREAM", "0")
+    want = sift.gau_blur(img, 6.4)
+    monkeypatch.setenv("SIFT_BLUR_STREAM", "1")
+    got = sift.gau_blur(img, 6.4)
+    assert np.array_equal(bits(got), bits(want))
+    del got, want
+    monkeypatch.delenv("SIFT_BLUR_STREAM", raising=False)
+
+
 def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
     """The one-launch form of the blur (row and column pass of a 64 x 64 tile through LDS; by
     itself only used on octaves of 3 Mpixel and more) forced onto small and ragged images: every
