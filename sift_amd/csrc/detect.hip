@@ -85,6 +85,32 @@ __device__ __forceinline__ void detect_four_rows(const float* s_dog, int ry0, in
     int rad[3];
 #pragma unroll
     for (int l = 0; l < 3; l++) rad[l] = lc[l].radius;
+    // Most strips of a smooth image hold no pixel above the contrast bar: look at that first (one read and
+    // one compare per pixel and layer) and leave with empty mask words if so.
+    {
+        unsigned long long any = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int y = y0 + ry0 + i;
+            if (y < H) {
+#pragma unroll
+                for (int l = 0; l < 3; l++) {
+                    const float v = s_dog[(l + 1) * LS + (ry0 + 1 + i) * DET_LW + lane + 1];
+                    const int rd = rad[l];
+                    const bool hit = (H >= 2 * rd + 3) && (W >= 2 * rd + 3) && y >= rd + 1 && y < H - rd - 1 && x >= rd + 1 &&
+                                     x < W - rd - 1 && (fabsf(v) > thr);
+                    any |= __ballot(hit);
+                }
+            }
+        }
+        if (any == 0) {
+            if (lane < 12) {
+                const int i = lane / 3, l = lane - 3 * i, y = y0 + ry0 + i;
+                if (y < H) masks[((size_t)l * H + y) * WW + tx] = 0ull;
+            }
+            return;
+        }
+    }
     float C[3][3], L[3][3], R[3][3];        // tested layers: value, left, right of the last three rows
     float hmax[NLAY][3], hmin[NLAY][3];     // per layer and row: max / min of (left, centre, right)
     const int hcol = lane == 0 ? 0 : DET_LW - 1;
