@@ -209,8 +209,48 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restric
         const int gx = min(x0 + lane, W - 1);
         const int hx = lane == 0 ? max(x0 - 1, 0) : min(x0 + 64, W - 1);
         const int hcol = lane == 0 ? 0 : DET_LW - 1;
-        if (NLAY > 0) {
-            // all loads of the tile in flight at once
+        if (NLAY > 0 && PX < ((size_t)1 << 30)) {
+            // All loads of the tile in flight at once.  Buffer loads: one resource per level, the row as a
+            // scalar byte offset, the column as a lane offset that is computed once, so a load costs no
+            // vector instruction; the halo columns are fetched by every lane (lanes 2..63 repeat lane 1's
+            // address and write to a spare word behind the tile) instead of under an execution mask.
+            constexpr int NL = NLAY > 0 ? NLAY : 1;
+            constexpr int NR = (DET_LH + 3) / 4;
+            __amdgpu_buffer_rsrc_t lvl[NL + 1];
+#pragma unroll
+            for (int k = 0; k <= NL; k++)
+                lvl[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gau + (size_t)k * PX), 0, (unsigned)(PX * 4), 0x00020000);
+            const int vx = gx * 4;
+            const int vh = (lane == 0 ? hx : min(x0 + 64, W - 1)) * 4;
+            const int uwave = __builtin_amdgcn_readfirstlane(wave);
+            float v[NR][NL + 1], hv[NR][NL + 1];
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                const int r = uwave + 4 * i;
+                const int gy = min(max(y0 + r - 1, 0), H - 1);
+                const int so = gy * W * 4;  // below 2^32: PX * 4 is
+#pragma unroll
+                for (int k = 0; k <= NL; k++) {
+                    v[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lvl[k], vx, so, 0));
+                    hv[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lvl[k], vh, so, 0));
+                }
+            }
+            const int spare = nlay * LS;                                    // one word behind the staged layers
+            const int hw = lane < 2 ? hcol : spare;                         // where this lane's halo value goes
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                const int r = uwave + 4 * i;
+                if (r < DET_LH) {
+                    float* dst = s_dog + r * DET_LW;
+#pragma unroll
+                    for (int k = 0; k < NL; k++) {
+                        dst[k * LS + lane + 1] = v[i][k] - v[i][k + 1];
+                        s_dog[lane < 2 ? k * LS + r * DET_LW + hw : hw] = hv[i][k] - hv[i][k + 1];
+                    }
+                }
+            }
+        } else if (NLAY > 0) {
+            // (levels of 4 GB and more: plain 64-bit addressing)
             constexpr int NL = NLAY > 0 ? NLAY : 1;
             constexpr int NR = (DET_LH + 3) / 4;
             float v[NR][NL + 1], hv[NR][NL + 1];
@@ -845,7 +885,7 @@ void launch_detect(sift_hip_ctx* ctx, OctWs& ws, int octave, size_t PX, int W, i
         ProfScope ps(ctx, SIFT_HIP_K_DETECT, ws.stream);
         hipMemsetAsync(ws.row_cnt.p, 0, (size_t)nrows * sizeof(int), ws.stream);
         const int nlay = intvls + 2 - lazy;
-        const size_t lds = (size_t)nlay * DET_LH * DET_LW * sizeof(float);
+        const size_t lds = ((size_t)nlay * DET_LH * DET_LW + 1) * sizeof(float);  // + a spare word (see the staging)
         auto kern = nlay == 5 ? detect_tile_kernel<5> : nlay == 4 ? detect_tile_kernel<4> : detect_tile_kernel<0>;
         hipLaunchKernelGGL(kern, dim3(WW, (H + DET_TR - 1) / DET_TR), dim3(256), lds, ws.stream,
                            (const float*)ws.gau_all.p, PX, W, H, intvls, d_lc, thr, WW,
