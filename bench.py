@@ -173,6 +173,14 @@ def main():
                                    os.path.basename(tpath)
             else:
                 traffic_note = "profiles/%s was measured on other kernel sources: not reported" % os.path.basename(tpath)
+        # Issue-slot utilisation of the two largest blur kernels (counter pass on one level, same hash rule)
+        valu_issue = None
+        ifiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue.json")))
+        if ifiles and args.blur_mode == 0:
+            ij = json.load(open(ifiles[-1]))
+            if ij.get("kernel_source_sha256") == src_hash:
+                valu_issue = {"source": "profiles/" + os.path.basename(ifiles[-1]), "workload": ij.get("workload"),
+                              "definition": ij.get("definition"), "kernels": ij.get("kernels")}
         # VALU floor of the exact blur: 4.56 ns per wave-level (half a v_pk_mul_f32, v_cvt_f64_f32, v_add_f64)
         # triple per SIMD (tools/microbench_valu.hip), 1024 SIMDs
         # levels built as images: the library evaluates the last level only around top-layer
@@ -208,6 +216,7 @@ def main():
                 "valu_floor_ms": round(valu_floor_ms, 4) if args.blur_mode == 0 else None,
                 "frac_of_valu_floor": round(valu_floor_ms / t_stage, 4) if args.blur_mode == 0 else None,
             },
+            "valu_issue": valu_issue,
             "avg_launch_ms_by_class": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items() if v[1]},
             "stage_ms_per_frame": {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1]},
             "note": "blur_mode 0 keeps the reference's float-product / double-accumulate arithmetic bit for bit, "

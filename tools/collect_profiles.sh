@@ -18,6 +18,9 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 tools/profile_extract.py --steps 2 > $out/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 tools/profile_extract.py --steps 2 > $out/pmc_write.log 2>&1
 python3 tools/summarize_pmc.py $out/pmc_fetch $out/pmc_write 2 > $out/traffic.json
+unset SIFT_HIP_SERIAL
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_issue -- python3 tools/profile_blur_level.py > $out/pmc_issue.log 2>&1
+python3 tools/summarize_issue.py $out/pmc_issue > $out/issue.json
 for d in stats4k stats1080 stats8k stats4k_fast; do cp $out/$d/*/*kernel_stats.csv $out/${d}_kernel_stats.csv; done
-rm -rf $out/stats4k $out/stats1080 $out/stats8k $out/stats4k_fast $out/pmc_fetch $out/pmc_write
+rm -rf $out/stats4k $out/stats1080 $out/stats8k $out/stats4k_fast $out/pmc_fetch $out/pmc_write $out/pmc_issue
 ls -la $out
