@@ -11,7 +11,8 @@
  *
  * Threading: a context is bound to one device and is not thread-safe.  Use one
  * context per GPU; distinct contexts may be driven concurrently from different
- * threads.  A context overlaps the octaves of a frame on several HIP streams of its own
+ * threads (one exception: sift_hip_match_u8_noalloc, whose work area is one static
+ * array per GPU shared by every context -- see its comment).  A context overlaps the octaves of a frame on several HIP streams of its own
  * and joins them on the host; no stream of the library ever waits on another
  * stream's event, so it cannot stall behind other users of the device's hardware
  * queues (further contexts, the caller's own streams, RCCL).
@@ -39,7 +40,10 @@ typedef enum sift_hip_status {
     SIFT_HIP_ERR_LIMIT = -7     /* an internal fixed limit was exceeded (candidate table) */
 } sift_hip_status;
 
-/* Compile-time tunables of Sift.hpp:44-77 that the path reads, as run-time fields. */
+/* Compile-time tunables of Sift.hpp:44-77 that the path reads, as run-time fields.
+ * Always start from sift_hip_default_params() and change fields: every field is validated
+ * (subpixel, blur_mode and textbook must be 0 or 1), so a struct with an uninitialised
+ * field is rejected with SIFT_HIP_ERR_ARG or, worse, selects a mode by accident. */
 typedef struct sift_hip_params {
     int32_t octaves;     /* 0 = the reference's own count, Sift.cpp:130-139 (getPyramidOctv) */
     int32_t intvls;      /* SIFT_INTVLS (3); Gaussian levels per octave = intvls + 3 */
@@ -308,6 +312,15 @@ enum {
     SIFT_HIP_K_BLUR_FUSED = 15, /* row and column pass of one level in one launch (short kernels, octaves of 3 Mpixel and more) */
     SIFT_HIP_K_COUNT = 16
 };
+/* Launch-shape switches of a context, for A/B measurements and tests (results never depend on
+ * them; no counterpart in the reference).  key / value: "blur_seg" rows per segment of the
+ * streaming column pass (0 = chosen per image); "blur_stream" -1 = where it pays, 0 = never,
+ * 1 = wherever an instance exists; "blur_fused" -1 = where it pays, else the longest kernel that
+ * takes the one-launch form at any image size; "match_nb" 0 = by query count, 2 or 4;
+ * "interleave" 0/1; "multi_octave" 0/1.  The same switches are read from the environment once,
+ * in sift_hip_create (SIFT_BLUR_SEG, SIFT_BLUR_STREAM, SIFT_BLUR_FUSED, SIFT_MATCH_NB,
+ * SIFT_HIP_INTERLEAVE, SIFT_HIP_MULTI_OCTAVE); no other call looks at the environment. */
+int sift_hip_set_tuning(sift_hip_ctx* ctx, const char* key, int value);
 int sift_hip_profile(sift_hip_ctx* ctx, int enable);
 /* Synchronises, then fills ms[k] = summed kernel time and launches[k] = launch
  * count of class k since the last reset; both arrays hold SIFT_HIP_K_COUNT entries. */

@@ -233,8 +233,13 @@ bool harris_corner(const Img& p, size_t w, size_t y, size_t x, float r) {
 }
 
 // Sift/Sift.cpp:250-295  getHistogramMS + FeatAppend (:229-249)
+// quality != 0 (the mode the reference's own notes ask for, update.md:9-10; nothing in the
+// reference to compare with): the weights come from weight_sigma, the orientation is the bin
+// centre moved by the vertex of the parabola through the peak bin and its two neighbours, in
+// whole degrees, and sigmaOCT keeps the un-truncated sigma.
 void histogram_ms(std::vector<Feat>& out, const Img& img, size_t W, float Insize, size_t intvl_idx,
-                  float sigma, size_t Iny, size_t Inx, size_t Inr, const float* sub = nullptr) {
+                  float sigma, size_t Iny, size_t Inx, size_t Inr, const float* sub = nullptr, int quality = 0,
+                  float weight_sigma = 0.f) {
     const size_t matLen = Inr * 2 + 1;
     std::vector<float> mag(matLen * matLen);
     std::vector<float> sita(matLen * matLen);
@@ -247,7 +252,7 @@ void histogram_ms(std::vector<Feat>& out, const Img& img, size_t W, float Insize
             sita[idx] = fast_atan2f(dy, dx);
         }
     }
-    std::vector<float> gauMat = gau_matrix(sigma, matLen);
+    std::vector<float> gauMat = gau_matrix(quality ? weight_sigma : sigma, matLen);
     for (size_t j = 0; j < matLen; j++)
         for (size_t i = 0; i < matLen; i++) mag[j * matLen + i] *= gauMat[i];
     for (size_t j = 0; j < matLen; j++)
@@ -270,6 +275,13 @@ void histogram_ms(std::vector<Feat>& out, const Img& img, size_t W, float Insize
             f.size = Insize;
             f.kai = (int)intvl_idx;
             f.sigmaOCT = (float)(int)sigma;  // FeatAppend takes sigmaOCT as int
+            if (quality) {
+                const float l = magSum[(i + 35) % 36], c0 = magSum[i], r = magSum[(i + 1) % 36];
+                const float den = l - 2.f * c0 + r;
+                const float off = den < 0.f ? std::fmin(std::fmax(0.5f * (l - r) / den, -0.5f), 0.5f) : 0.f;
+                f.sita = ((int)std::lround(10.f * ((float)i + 0.5f + off)) + 360) % 360;
+                f.sigmaOCT = sigma;
+            }
             if (sub) std::memcpy(f.sub, sub, sizeof f.sub);
             out.push_back(f);
         }
@@ -346,6 +358,31 @@ void descr_hist(float* hist, const Img& img, int col, int row, int r, int c, flo
             }
         }
     }
+}
+
+// The descriptor the quality mode computes: Sift.cpp:342-387 with the orientation in RADIANS
+// (Sift.cpp:351-352 feed degrees to cos/sin), measured in the sense the gradient angles of
+// calc_grad_mag_ori are (row axis up, Sift.cpp:306; the orientation histogram measures with the
+// row axis down, Sift.cpp:262, hence the minus sign), and the un-truncated sigma.
+void descr_hist_quality(float* hist, const Img& img, int col, int row, int r, int c, int sita_deg, float scl,
+                        int d, int n) {
+    const float ori = -(float)sita_deg * (float)(kPi / 180.0);
+    descr_hist(hist, img, col, row, r, c, ori, scl, d, n);
+}
+
+// Sift/Sift.cpp:389-399 normalize_descr as it was meant (over all 128 entries), then
+// Sift.cpp:409-415: normalise, clamp at 0.2, normalise again, times 512, min 255.
+void hist_to_descr_quality(Feat& f) {
+    for (int pass = 0; pass < 2; pass++) {
+        float len_sq = 0.f;
+        for (int i = 0; i < 128; i++) len_sq += f.hist[i] * f.hist[i];
+        const float len_inv = len_sq > 0.f ? 1.f / std::sqrt(len_sq) : 0.f;
+        for (int i = 0; i < 128; i++) f.hist[i] *= len_inv;
+        if (pass == 0)
+            for (int i = 0; i < 128; i++)
+                if (f.hist[i] > (float)kDescrMagThr) f.hist[i] = (float)kDescrMagThr;
+    }
+    for (int i = 0; i < 128; i++) f.descr[i] = (float)std::min(255, (int)(kIntDescrFctr * f.hist[i]));
 }
 
 // Sift/Sift.cpp:400-421  hist_to_descr.  Both normalize_descr() calls
@@ -468,7 +505,11 @@ struct Octave {
 
 // One iteration of the octave loop of Sift::pyramid (Sift/Sift.cpp:145-168):
 // resample from the ORIGINAL image, 6 cascaded blurs with absolute sigmas, DoG.
-void build_octave(Octave& oc, const Img& gray, size_t w, size_t h, size_t ph, size_t pyWidth) {
+// quality != 0: the ladder the reference's notes call for (update.md:10 doubts the sigmas of
+// Sift.cpp:152-157): level i holds sigma0 * sqrt(2)^i in octave pixels at EVERY octave, reached
+// from the level below by the increment sqrt(s_i^2 - s_below^2); the resampled image counts as
+// blurred by half a source pixel.
+void build_octave(Octave& oc, const Img& gray, size_t w, size_t h, size_t ph, size_t pyWidth, int quality = 0) {
     float curr_size = 2.f, coef = 1.f;
     for (size_t k = 0; k < ph; k++) { curr_size /= 2.f; coef *= 2.f; }
     Img cur;
@@ -477,10 +518,20 @@ void build_octave(Octave& oc, const Img& gray, size_t w, size_t h, size_t ph, si
     oc.W = (int)W;
     oc.H = (int)H;
     oc.gau.assign(pyWidth, Img());
+    if (quality) {
+        float below = std::max(0.5f * curr_size, 0.1f);
+        for (size_t i = 0; i < pyWidth; i++) {
+            const float s = kGauSigma * powf(std::sqrt(2.0), i);
+            const float s_blur = std::sqrt(std::max(s * s - below * below, 0.01f));
+            gau_blur(oc.gau[i], i == 0 ? cur : oc.gau[i - 1], W, H, s_blur);
+            below = s;
+        }
+    } else {
     gau_blur(oc.gau[0], cur, W, H, kGauSigma * coef);
     for (size_t i = 1; i < pyWidth; i++) {
         const float curr_Sigma = kGauSigma * powf(std::sqrt(2.0), i) * coef;
         gau_blur(oc.gau[i], oc.gau[i - 1], W, H, curr_Sigma);
+    }
     }
     oc.dog.assign(pyWidth - 1, Img());
     for (size_t i = 0; i < pyWidth - 1; i++) {
@@ -495,14 +546,30 @@ void build_octave(Octave& oc, const Img& gray, size_t w, size_t h, size_t ph, si
 // a rejected point is dropped, an accepted one is moved to the refined (layer,
 // row, column) and keeps the offsets; the orientation window must still fit the
 // image at the new place (the scan bounds of the new layer), else it is dropped.
+// quality != 0: windows of radius 3 x (1.5 sigma) weighted by 1.5 sigma with sigma the layer's
+// own in octave pixels, refinement always on with the contrast bar per interval
+// (contr_thr / intvls, the rule matrix.hpp:181 keeps commented out), interpolated orientation,
+// radian descriptor frame, normalised descriptor.
 void detect_octave(std::vector<Feat>& feats, const Octave& oc, size_t ph, size_t pyWidth, int describe,
-                   int subpixel = 0, double contr_thr = 0.05) {
+                   int subpixel = 0, double contr_thr = 0.05, int quality = 0) {
     float curr_size = 2.f, coef = 1.f;
     for (size_t k = 0; k < ph; k++) { curr_size /= 2.f; coef *= 2.f; }
     const size_t W = oc.W, H = oc.H;
     const size_t firstNew = feats.size();
+    const int intvls = (int)pyWidth - 3;
+    if (quality) {
+        subpixel = 1;
+        contr_thr = (double)((float)contr_thr / (float)intvls);
+    }
+    auto layer_sigma = [&](size_t li) -> float {
+        return quality ? kGauSigma * powf(std::sqrt(2.0), li) : kGauSigma * powf(std::sqrt(2.0), li) * coef;
+    };
+    auto layer_radius = [&](size_t li) -> size_t {
+        if (quality) return (size_t)std::lround(3.0 * (1.5f * layer_sigma(li)));
+        return (size_t)(curr_size * 3. * 1.5 * (li + 1));
+    };
     for (size_t intvl_idx = 1; intvl_idx < pyWidth - 1 - 1; intvl_idx++) {
-        const size_t r = curr_size * 3. * 1.5 * (intvl_idx + 1);
+        const size_t r = layer_radius(intvl_idx);
         // The reference's unsigned bounds wrap when the octave is smaller than
         // the window; such octaves contribute nothing here.
         if (H < 2 * r + 3 || W < 2 * r + 3) continue;
@@ -510,7 +577,7 @@ void detect_octave(std::vector<Feat>& feats, const Octave& oc, size_t ph, size_t
             for (size_t i = r + 1; i < W - r - 1; i++) {
                 if (find_max_min(oc.dog, intvl_idx, W, j, i)) {
                     const Img& cur = oc.dog[intvl_idx];
-                    const float currSigma = kGauSigma * powf(std::sqrt(2.0), intvl_idx) * coef;
+                    const float currSigma = layer_sigma(intvl_idx);
                     if (harris_corner(cur, W, j, i, r)) {
                         if (!subpixel) {
                             histogram_ms(feats, cur, W, curr_size, intvl_idx, currSigma, j, i, r);
@@ -520,12 +587,12 @@ void detect_octave(std::vector<Feat>& feats, const Octave& oc, size_t ph, size_t
                         float sub[3];
                         if (!interp_extremum(oc.dog, (int)W, (int)H, li, rr, cc, (int)pyWidth - 3, contr_thr, sub))
                             continue;
-                        const size_t r2 = curr_size * 3. * 1.5 * (li + 1);
+                        const size_t r2 = layer_radius((size_t)li);
                         if (H < 2 * r2 + 3 || W < 2 * r2 + 3 || (size_t)rr < r2 + 1 || (size_t)rr >= H - r2 - 1 ||
                             (size_t)cc < r2 + 1 || (size_t)cc >= W - r2 - 1)
                             continue;
-                        const float sigma2 = kGauSigma * powf(std::sqrt(2.0), (size_t)li) * coef;
-                        histogram_ms(feats, oc.dog[li], W, curr_size, li, sigma2, rr, cc, r2, sub);
+                        const float sigma2 = layer_sigma((size_t)li);
+                        histogram_ms(feats, oc.dog[li], W, curr_size, li, sigma2, rr, cc, r2, sub, quality, 1.5f * sigma2);
                     }
                 }
             }
@@ -536,6 +603,11 @@ void detect_octave(std::vector<Feat>& feats, const Octave& oc, size_t ph, size_t
     for (size_t k = firstNew; k < feats.size(); k++) {
         Feat& f = feats[k];
         const Img& img = oc.gau[f.kai];
+        if (quality) {
+            descr_hist_quality(f.hist, img, (int)W, (int)H, f.y, f.x, f.sita, f.sigmaOCT, kDescrHistRadius, kDescrHistBins);
+            hist_to_descr_quality(f);
+            continue;
+        }
         int ori = f.sita;
         int scl = (int)f.sigmaOCT;
         descr_hist(f.hist, img, (int)W, (int)H, f.y, f.x, (float)ori, (float)scl, kDescrHistRadius,
@@ -614,17 +686,17 @@ void orc_octave_levels(const float* gray, int w, int h, int octave, int intvls, 
 // hist_out (optional): n x 128 clamped raw histograms.  Returns feature count
 // (the full count even when it exceeds cap; only cap entries are written).
 // sub_out (optional): n x 3 sub-pixel offsets (xc, xr, xi).
-int orc_extract_ex(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,
-                   float* hist_out, int describe, int subpixel, double contr_thr, float* sub_out) {
+static int extract_impl(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,
+                        float* hist_out, int describe, int subpixel, double contr_thr, float* sub_out, int quality) {
     Img g(gray, gray + (size_t)w * h);
     const size_t pyWidth = intvls + 3;
     size_t octvs = octaves > 0 ? (size_t)octaves : pyramid_octaves(w, h);
     std::vector<Feat> feats;
     for (size_t ph = 0; ph < octvs; ph++) {
         Octave oc;
-        build_octave(oc, g, w, h, ph, pyWidth);
+        build_octave(oc, g, w, h, ph, pyWidth, quality);
         if (oc.W < 2 || oc.H < 2) break;
-        detect_octave(feats, oc, ph, pyWidth, describe, subpixel, contr_thr);
+        detect_octave(feats, oc, ph, pyWidth, describe, subpixel, contr_thr, quality);
     }
     const int n = (int)feats.size();
     for (int k = 0; k < n && k < cap; k++) {
@@ -637,6 +709,18 @@ int orc_extract_ex(const float* gray, int w, int h, int octaves, int intvls, orc
         if (sub_out) std::memcpy(sub_out + (size_t)k * 3, f.sub, 3 * 4);
     }
     return n;
+}
+
+int orc_extract_ex(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,
+                   float* hist_out, int describe, int subpixel, double contr_thr, float* sub_out) {
+    return extract_impl(gray, w, h, octaves, intvls, out, cap, hist_out, describe, subpixel, contr_thr, sub_out, 0);
+}
+
+// The quality mode (see build_octave / detect_octave / histogram_ms); sigmaOCT comes back
+// un-truncated, hist_out holds the normalised, clamped, re-normalised histograms.
+int orc_extract_quality(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,
+                        float* hist_out, double contr_thr, float* sub_out) {
+    return extract_impl(gray, w, h, octaves, intvls, out, cap, hist_out, 1, 1, contr_thr, sub_out, 1);
 }
 
 int orc_extract(const float* gray, int w, int h, int octaves, int intvls, orc_feat* out, int cap,

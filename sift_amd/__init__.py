@@ -16,4 +16,4 @@ from .capi import (  # noqa: F401
     load_library,
     pyramid_octaves,
 )
-from .synth import blob_image, planted_descriptors  # noqa: F401
+from .synth import blob_image, planted_descriptors, textured_image  # noqa: F401

@@ -132,6 +132,7 @@ def load_library() -> C.CDLL:
         "sift_hip_multiband_blend_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "sift_hip_panorama_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                              C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
+        "sift_hip_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
         "sift_hip_kernel_class_name": (C.c_char_p, [C.c_int]),
@@ -417,6 +418,10 @@ class SiftHip:
         return canvas
 
     # ---- measurement ----------------------------------------------------------------
+    def set_tuning(self, key: str, value: int):
+        """Launch-shape switch of this context (sift_hip_set_tuning); results never depend on it."""
+        self._check(self.lib.sift_hip_set_tuning(self.h, key.encode(), int(value)))
+
     def profile(self, enable: bool):
         self._check(self.lib.sift_hip_profile(self.h, int(enable)))
 

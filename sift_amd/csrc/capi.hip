@@ -3,6 +3,7 @@
 // sequence of the extract and match paths.  No CPU fallback exists: every entry
 // point that does image or descriptor arithmetic runs the HIP kernels.
 #include <algorithm>
+#include <cctype>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -24,10 +25,20 @@ bool hip_ok(sift_hip_ctx* ctx, hipError_t e, const char* what) {
     return false;
 }
 
+// Waits on the host for everything the context has enqueued on its compute streams.
+void join_all(sift_hip_ctx* ctx) {
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->side_busy) {
+        if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
+        if (ctx->side_stream2) hipStreamSynchronize(ctx->side_stream2);
+        if (ctx->side_stream3) hipStreamSynchronize(ctx->side_stream3);
+    }
+}
+
 int ensure(sift_hip_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return SIFT_HIP_OK;
     if (b.p) {
-        hipStreamSynchronize(ctx->stream);
+        join_all(ctx);
         hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
@@ -377,7 +388,7 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         }
         return r;
     };
-    static const bool interleave = [] { const char* e = std::getenv("SIFT_HIP_INTERLEAVE"); return !e || e[0] != '0'; }();
+    const bool interleave = ctx->tune.interleave != 0;
     // (not in the batch pipeline, where the previous frame's tail keeps the device busy meanwhile and
     // launching octave by octave measured 5 % faster)
     if (interleave && !ctx->pipelined && !serial && ctx->n_side >= 2 && noct > 2) {
@@ -613,7 +624,7 @@ static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Fetche
         rc = enqueue_extract(ctx, d, w, h, prm, cap, cand_cap, false, 0);
         ctx->pipelined = false;
         if (rc) {
-            hipStreamSynchronize(ctx->stream);
+            join_all(ctx);
             return rc;
         }
         hipEventRecord(ctx->ev_frame[f & 1], ctx->stream);
@@ -637,12 +648,12 @@ static int extract_batch_pipelined(sift_hip_ctx* ctx, FramePtr frame_ptr, Fetche
             swap_output_sets(ctx);
             fetched(f - 1);
             if (overflow) {
-                hipStreamSynchronize(ctx->stream);
+                join_all(ctx);
                 return plain_from(f - 1);
             }
             if (rc == SIFT_HIP_ERR_NOSPC) worst = rc;
             else if (rc) {
-                hipStreamSynchronize(ctx->stream);
+                join_all(ctx);
                 return rc;
             }
         }
@@ -687,6 +698,15 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     if (const char* e = std::getenv("SIFT_HIP_FULL_TOP")) ctx->full_top_level = (e[0] == '1');
     if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("SIFT_HIP_NSIDE")) ctx->n_side = (e[0] == '1') ? 1 : 2;
+    // launch-shape switches: looked up here once, never on a launch path
+    for (const char* key : {"blur_seg", "blur_stream", "blur_fused", "match_nb", "interleave", "multi_octave"}) {
+        std::string name = key == std::string("interleave") ? "SIFT_HIP_INTERLEAVE"
+                         : key == std::string("match_nb")   ? "SIFT_MATCH_NB"
+                         : key == std::string("multi_octave") ? "SIFT_HIP_MULTI_OCTAVE"
+                                                            : std::string("SIFT_") + key;
+        for (char& c : name) c = (char)std::toupper((unsigned char)c);
+        if (const char* e = std::getenv(name.c_str())) sift_hip_set_tuning(ctx, key, std::atoi(e));
+    }
     // the small octaves' stream gets the more urgent priority: their kernels are short and
     // latency-bound and would otherwise queue behind octave 0's large grids
     int prio_lo = 0, prio_hi = 0;
@@ -788,6 +808,20 @@ const char* sift_hip_strerror(int s) {
         case SIFT_HIP_ERR_LIMIT: return "internal limit exceeded";
         default: return "unknown status";
     }
+}
+
+int sift_hip_set_tuning(sift_hip_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return SIFT_HIP_ERR_ARG;
+    const std::string k(key);
+    Tuning& t = ctx->tune;
+    if (k == "blur_seg") t.blur_seg = std::max(0, value);
+    else if (k == "blur_stream") t.blur_stream = value < 0 ? -1 : (value != 0);
+    else if (k == "blur_fused") t.blur_fused = value < 0 ? -1 : value;
+    else if (k == "match_nb") { if (value != 0 && value != 2 && value != 4) return SIFT_HIP_ERR_ARG; t.match_nb = value; }
+    else if (k == "interleave") t.interleave = value != 0;
+    else if (k == "multi_octave") t.multi_octave = value != 0;
+    else return SIFT_HIP_ERR_ARG;
+    return SIFT_HIP_OK;
 }
 
 const char* sift_hip_last_error(const sift_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
@@ -977,10 +1011,10 @@ int sift_hip_octave_levels(sift_hip_ctx* ctx, const float* gray, int w, int h, c
                            int octave, float* gau, float* dog, int* ow, int* oh) {
     if (bad_ctx(ctx) || !gray || w < 2 || h < 2 || octave < 0 || !ow || !oh) return SIFT_HIP_ERR_ARG;
     sift_hip_params prm;
-    if (params) prm = *params; else sift_hip_default_params(&prm);
-    if (prm.intvls < 1 || prm.intvls > 8 || prm.octaves < 0 || prm.octaves > 24 || !(prm.sigma0 > 0.f))
-        return SIFT_HIP_ERR_ARG;
-    if ((long long)w * h * 4 >= (1ll << 31)) return SIFT_HIP_ERR_LIMIT;
+    {
+        const int vrc = checked_params(params, w, h, &prm);
+        if (vrc) return vrc;
+    }
     if (prm.octaves > 0 && prm.octaves <= octave) prm.octaves = octave + 1;
     int rc = build_plan(ctx, w, h, prm);
     if (rc) return rc;
@@ -1247,12 +1281,14 @@ int sift_hip_multiband_blend(sift_hip_ctx* ctx, uint8_t* l_rgb, int lw, int lh, 
     int rc;
     if ((rc = ensure(ctx, ctx->blend_l, lb))) return rc;
     if ((rc = ensure(ctx, ctx->blend_r, rb))) return rc;
-    hipMemcpyAsync(ctx->blend_l.p, l_rgb, lb, hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(ctx->blend_r.p, r_rgb, rb, hipMemcpyHostToDevice, ctx->stream);
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->blend_l.p, l_rgb, lb, hipMemcpyHostToDevice, ctx->stream), "upload left image") ||
+        !hip_ok(ctx, hipMemcpyAsync(ctx->blend_r.p, r_rgb, rb, hipMemcpyHostToDevice, ctx->stream), "upload right image"))
+        return SIFT_HIP_ERR_HIP;
     rc = sift_hip_multiband_blend_dev(ctx, (uint8_t*)ctx->blend_l.p, lw, lh, (uint8_t*)ctx->blend_r.p, rw, rh, dx, dy);
     if (rc) return rc;
-    hipMemcpyAsync(l_rgb, ctx->blend_l.p, lb, hipMemcpyDeviceToHost, ctx->stream);
-    hipMemcpyAsync(r_rgb, ctx->blend_r.p, rb, hipMemcpyDeviceToHost, ctx->stream);
+    if (!hip_ok(ctx, hipMemcpyAsync(l_rgb, ctx->blend_l.p, lb, hipMemcpyDeviceToHost, ctx->stream), "download left image") ||
+        !hip_ok(ctx, hipMemcpyAsync(r_rgb, ctx->blend_r.p, rb, hipMemcpyDeviceToHost, ctx->stream), "download right image"))
+        return SIFT_HIP_ERR_HIP;
     if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "multiband_blend")) return SIFT_HIP_ERR_HIP;
     return check_async(ctx, "multiband_blend");
 }

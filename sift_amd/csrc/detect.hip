@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const float* __restric
             for (int i = 0; i < NR; i++) {
                 const int r = uwave + 4 * i;
                 const int gy = min(max(y0 + r - 1, 0), H - 1);
-                const int so = gy * W * 4;  // below 2^32: PX * 4 is
+                const int so = (int)((unsigned)gy * (unsigned)W * 4u);  // unsigned product: below 2^32, PX * 4 is
 #pragma unroll
                 for (int k = 0; k <= NL; k++) {
                     v[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lvl[k], vx, so, 0));

@@ -69,6 +69,19 @@ struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-18
     std::vector<int> wts_off;      // per layer: offset of the orientation weights
 };
 
+// Launch-shape switches for A/B measurements and tests.  They are read from the environment
+// once, when the context is created (SIFT_BLUR_SEG, SIFT_BLUR_STREAM, SIFT_BLUR_FUSED,
+// SIFT_MATCH_NB, SIFT_HIP_INTERLEAVE), and changed on a live context only through
+// sift_hip_set_tuning: no launch path looks at the environment.
+struct Tuning {
+    int blur_seg = 0;      // streaming column pass: rows per segment (0 = chosen per image)
+    int blur_stream = -1;  // streaming column pass: -1 = where it pays, 0 = never, 1 = wherever an instance exists
+    int blur_fused = -1;   // one-launch blur: -1 = where it pays, else the longest kernel that takes it at any image size
+    int match_nb = 0;      // matcher: 32-query blocks per wave, 0 = by query count, else 2 or 4
+    int interleave = 1;    // single frames: pyramids of the streams' first octaves enqueued level by level in turn
+    int multi_octave = 1;  // the small octaves' blur passes of one level share a launch
+};
+
 struct Plan {
     int w = 0, h = 0;
     sift_hip_params prm{};
@@ -117,6 +130,8 @@ struct sift_hip_ctx {
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
     sifthip::DevBuf h_feat, h_hist;
 
+    sifthip::Tuning tune;
+
     // profiling
     bool profiling = false;
     bool force_serial = false;
@@ -135,6 +150,7 @@ namespace sifthip {
 // Returns false and records the message in ctx->last_error on failure.
 bool hip_ok(sift_hip_ctx* ctx, hipError_t e, const char* what);
 int ensure(sift_hip_ctx* ctx, DevBuf& b, size_t bytes);
+void join_all(sift_hip_ctx* ctx);  // host wait for every compute stream of the context with work pending
 int ensure_pinned(sift_hip_ctx* ctx, DevBuf& b, size_t bytes);
 void prof_begin(sift_hip_ctx* ctx, int cls, hipStream_t st);
 void prof_end(sift_hip_ctx* ctx, hipStream_t st);

@@ -346,15 +346,14 @@ static void launch_match(hipStream_t st, bool big, const uint8_t* d_q, int nq, i
                            ratio_form, d_best, d_d1, d_d2);
 }
 
-static bool match_big(int nq) {
-    bool big = nq >= 512 * 512;  // >= 2 workgroups of 512 queries per CU
-    if (const char* e = std::getenv("SIFT_MATCH_NB")) big = (e[0] == '4');
-    return big;
+static bool match_big(const sift_hip_ctx* ctx, int nq) {
+    if (ctx->tune.match_nb) return ctx->tune.match_nb == 4;
+    return nq >= 512 * 512;  // >= 2 workgroups of 512 queries per CU
 }
 
 int run_match(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio, int ratio_form,
               int32_t* d_best, int32_t* d_d1, int32_t* d_d2) {
-    const bool big = match_big(nq);
+    const bool big = match_big(ctx, nq);
     const int qpb = big ? 512 : 256;
     const int nq_pad = (nq + qpb - 1) / qpb * qpb;
     const int nr_pad = (nr + RT - 1) / RT * RT;
@@ -382,7 +381,7 @@ constexpr size_t kScrR = kScrQ + (size_t)kNoAllocMax * 128;            // int8 r
 constexpr size_t kScrQn = kScrR + (size_t)kNoAllocMax * 128;           // query norms
 constexpr size_t kScrRc = kScrQn + (size_t)kNoAllocMax * 4;            // reference constants (two ints per row)
 constexpr size_t kScrBytes = kScrRc + (size_t)kNoAllocMax * 8;
-static_assert(kNoAllocMax % 512 == 0 && kNoAllocMax >= RT, "padding must stay inside the array");
+static_assert(kNoAllocMax % 512 == 0 && kNoAllocMax >= RT && kNoAllocMax % RT == 0, "padding must stay inside the array");
 static __device__ __align__(256) unsigned char scratch[kScrBytes];
 
 static unsigned char* g_scratch_ptr[64];  // per device: address of that device's copy of `scratch`
@@ -417,6 +416,7 @@ int run_match_noalloc(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8
     // Every row the kernels read (up to nq_pad / nr_pad) is rewritten by the two
     // preparation launches, padding rows included, so nothing of an earlier call's
     // contents is ever looked at and nothing has to be cleared.
+    ProfScope ps(ctx, SIFT_HIP_K_MATCH, ctx->stream);  // does nothing unless profiling is on (which creates events)
     launch_match(ctx->stream, big, d_q, nq, nq_pad, d_r, nr, nr_pad, (int8_t*)(w + kScrQ), (int*)(w + kScrQn),
                  (int8_t*)(w + kScrR), (int*)(w + kScrRc), ratio, ratio_form, d_best, d_d1, d_d2);
     return SIFT_HIP_OK;

@@ -781,8 +781,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(StreamGeom<K
 // other and the pass takes as long as the fullest SIMD: the segments are cut so that the waves
 // come to about one full set of resident waves, rather a little less than a little more.
 template <int K>
-static int stream_segment(int W, int H) {
-    if (const char* e = std::getenv("SIFT_BLUR_SEG")) return (std::max(1, std::atoi(e)) + K - 1) / K * K;
+static int stream_segment(const sift_hip_ctx* ctx, int W, int H) {
+    if (ctx->tune.blur_seg > 0) return (ctx->tune.blur_seg + K - 1) / K * K;
     const long cols = (W + 63) / 64;
     const long slots = 1024L * StreamGeom<K>::WAVES;
     auto waves = [&](long m) { return cols * ((H + m * K - 1) / (m * K)); };
@@ -792,8 +792,9 @@ static int stream_segment(int W, int H) {
 }
 
 template <int K>
-static bool launch_col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps) {
-    int seg = stream_segment<K>(W, H);
+static bool launch_col_stream(const sift_hip_ctx* ctx, hipStream_t st, const float* tmp, float* dst, int W, int H,
+                              const float* d_taps) {
+    int seg = stream_segment<K>(ctx, W, H);
     // the kernel addresses the rows of a segment with 32-bit byte offsets: very wide images get shorter segments
     const long max_rows = (((long)1 << 31) - 1) / ((long)W * 4) - K;
     if (max_rows < K) return false;
@@ -805,21 +806,22 @@ static bool launch_col_stream(hipStream_t st, const float* tmp, float* dst, int 
 }
 
 // true if a streaming kernel exists for this tap count (the pyramid's own short kernels)
-static bool col_stream(hipStream_t st, const float* tmp, float* dst, int W, int H, const float* d_taps, int K) {
-    if (const char* e = std::getenv("SIFT_BLUR_STREAM")) {
-        if (e[0] == '0') return false;
+static bool col_stream(const sift_hip_ctx* ctx, hipStream_t st, const float* tmp, float* dst, int W, int H,
+                       const float* d_taps, int K) {
+    if (ctx->tune.blur_stream >= 0) {
+        if (ctx->tune.blur_stream == 0) return false;
     } else if ((size_t)((W + 63) / 64) * ((H + K - 1) / K) < 2048) {
         // even the shortest segments give fewer than two waves per SIMD: the tiled pass spreads better
         // (measured on 1920 x 1080: 39 taps 14 us tiled, 13-18 streaming; 55 taps 17 against 30)
         return false;
     }
     switch (K) {
-        case 11: return launch_col_stream<11>(st, tmp, dst, W, H, d_taps);
-        case 15: return launch_col_stream<15>(st, tmp, dst, W, H, d_taps);
-        case 21: return launch_col_stream<21>(st, tmp, dst, W, H, d_taps);
-        case 29: return launch_col_stream<29>(st, tmp, dst, W, H, d_taps);
-        case 39: return launch_col_stream<39>(st, tmp, dst, W, H, d_taps);
-        case 55: return launch_col_stream<55>(st, tmp, dst, W, H, d_taps);
+        case 11: return launch_col_stream<11>(ctx, st, tmp, dst, W, H, d_taps);
+        case 15: return launch_col_stream<15>(ctx, st, tmp, dst, W, H, d_taps);
+        case 21: return launch_col_stream<21>(ctx, st, tmp, dst, W, H, d_taps);
+        case 29: return launch_col_stream<29>(ctx, st, tmp, dst, W, H, d_taps);
+        case 39: return launch_col_stream<39>(ctx, st, tmp, dst, W, H, d_taps);
+        case 55: return launch_col_stream<55>(ctx, st, tmp, dst, W, H, d_taps);
         default: return false;
     }
 }
@@ -950,15 +952,15 @@ static bool launch_fused(sift_hip_ctx* ctx, hipStream_t st, const float* src, fl
 
 // whether the one-launch form is the choice for this level
 template <typename ACC>
-static bool fused_wanted(int W, int H, int K) {
+static bool fused_wanted(const sift_hip_ctx* ctx, int W, int H, int K) {
     // exact arithmetic: up to 29 taps (beyond, the extra row-pass work costs more than the second
     // trip through memory saves); float arithmetic: every length that has an instance
     const size_t px = (size_t)W * H;
     // (images of 16 Mpixel and more have the streaming column pass, which moves the break-even down)
     int max_k = sizeof(ACC) == sizeof(double) ? (px >= ((size_t)16 << 20) ? 15 : 29) : 39;
     size_t min_px = (size_t)3 << 20;  // smaller octaves: too few 64 x 64 tiles to fill the chip
-    if (const char* e = std::getenv("SIFT_BLUR_FUSED")) {  // A/B and test switch: longest kernel, any image size
-        max_k = std::atoi(e);
+    if (ctx->tune.blur_fused >= 0) {  // A/B and test switch: longest kernel, any image size
+        max_k = ctx->tune.blur_fused;
         min_px = 0;
     }
     return K <= max_k && px >= min_px && (K == 11 || K == 15 || K == 21 || K == 29 || K == 39);
@@ -981,7 +983,7 @@ static bool blur_fused(sift_hip_ctx* ctx, hipStream_t st, const float* src, floa
 template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                            const float* d_taps, int K) {
-    if (src != dst && fused_wanted<ACC>(W, H, K)) {
+    if (src != dst && fused_wanted<ACC>(ctx, W, H, K)) {
         ProfScope ps(ctx, SIFT_HIP_K_BLUR_FUSED, st);
         if (blur_fused<ACC>(ctx, st, src, dst, W, H, d_taps, K)) return;
     }
@@ -1009,7 +1011,7 @@ static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, 
     {
         ProfScope ps(ctx, (size_t)W * H >= ((size_t)3 << 20) ? SIFT_HIP_K_BLUR_COL : SIFT_HIP_K_BLUR_COL_SMALL, st);
         if constexpr (sizeof(ACC) == sizeof(double)) {
-            if (col_stream(st, tmp, dst, W, H, d_taps, K)) return;
+            if (col_stream(ctx, st, tmp, dst, W, H, d_taps, K)) return;
         }
         if ((size_t)W * H < ((size_t)1 << 16) && (size_t)H * 256 + (size_t)(K + 64) * sizeof(float) <= (size_t)kMaxColLds) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_col_tiny_kernel<ACC>), dim3((W + 63) / 64, (H + 3) / 4), dim3(256),

@@ -54,6 +54,24 @@ def blob_image(w: int, h: int, seed: int = 1, shift_x: int = 0, as_u8: bool = Fa
     return (u8.astype(np.float32).astype(np.float64) / 255.0).astype(np.float32)
 
 
+def textured_image(w: int, h: int, seed: int = 3) -> np.ndarray:
+    """Dense, anisotropic content: band-passed noise at four scales (sigma 1.5 ... 12 pixels) on top
+    of the blob field, float32 in [0, 1].  Where blob_image leaves most of a frame smooth, nearly
+    every pixel of this one passes the detector's contrast bar, and its structure has direction
+    (isotropic blobs look the same in any descriptor frame)."""
+    from scipy import ndimage
+
+    tex = np.zeros((h, w), np.float64)
+    for k, (sigma, weight) in enumerate(((1.5, 1.0), (3.0, 1.0), (6.0, 1.2), (12.0, 1.5))):
+        u1 = np.maximum(_uniform(seed, 20 + 2 * k, w * h), 1e-300)
+        u2 = _uniform(seed, 21 + 2 * k, w * h)
+        noise = (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).reshape(h, w)
+        n = ndimage.gaussian_filter(noise, sigma)
+        tex += weight * n / n.std()
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    return (0.6 * tex + 0.4 * blob_image(w, h, seed=seed)).astype(np.float32)
+
+
 def planted_descriptors(nq: int, nr: int, seed_q: int = 2, seed_r: int = 3, vmax: int = 102, plant: float = 0.01):
     """Query / reference byte descriptors: i.i.d. values in [0, vmax], with a
     fraction `plant` of the queries replaced by a noisy copy of some reference so

@@ -47,6 +47,7 @@ class Oracle:
         o.orc_extract.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
         o.orc_extract_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int,
                                      C.c_double, vp]
+        o.orc_extract_quality.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_double, vp]
         o.orc_force_match.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp]
         o.orc_match_u8.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]
         o.orc_warp_perspective.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]
@@ -167,6 +168,21 @@ class Oracle:
             sub = np.zeros((cap, 3), np.float32)
             n = self.o.orc_extract_ex(_p(gray), w, h, octaves, intvls, _p(out), cap, _p(hist), int(describe),
                                       int(subpixel), C.c_double(contr_thr), _p(sub))
+            if n > cap:
+                cap = n
+                continue
+            return out[:n], hist[:n], sub[:n]
+
+    def extract_quality(self, gray, octaves=0, intvls=3, cap=1 << 16, contr_thr=0.05):
+        """The quality mode (params.textbook = 1 of the product): -> (features, normalised histograms, offsets)."""
+        gray = np.ascontiguousarray(gray, np.float32)
+        h, w = gray.shape
+        while True:
+            out = np.zeros(cap, FEAT_DTYPE)
+            hist = np.zeros((cap, 128), np.float32)
+            sub = np.zeros((cap, 3), np.float32)
+            n = self.o.orc_extract_quality(_p(gray), w, h, octaves, intvls, _p(out), cap, _p(hist),
+                                           C.c_double(contr_thr), _p(sub))
             if n > cap:
                 cap = n
                 continue

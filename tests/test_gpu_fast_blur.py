@@ -10,11 +10,12 @@ from sift_amd import SiftParams
 
 pytestmark = pytest.mark.gpu
 
-# measured on the three inputs below: 99.95-100 % of the oracle's keypoints have a partner, 99.6-100 %
-# of the fast mode's have one in the oracle's set (the extra ones are near-ties of the non-strict
-# extremum test); descriptors of pairs at identical positions differ by at most one byte in a few places
-MIN_PARTNER_FRACTION = 0.99
-MAX_DESCR_L2 = 0.01          # on the clamped-histogram scale (bytes / 512); north star: 1e-3 before quantisation, one byte = 1/512
+# The bars are the ones stated for non-exact stages: every keypoint has a partner within 0.5 source
+# pixels at the same scale, layer and orientation (the few that do not are near-ties of the non-strict
+# extremum test, counted and bounded below), and the UNQUANTISED descriptors (the clamped histograms
+# that the bytes are cut from) of keypoints at identical positions are within 1e-3 in L2.
+MAX_UNPARTNERED = 0.005      # fraction of either set without a partner (measured: 0 .. 0.4 %)
+MAX_HIST_L2 = 1e-3           # clamped histograms of exact-position pairs, before quantisation
 MAX_LEVEL_ABS_ERR = 2e-6     # Gaussian levels of a [0, 1] image (measured 4.8e-7 .. 6.6e-7)
 
 
@@ -23,10 +24,13 @@ def key(f):
                      f["y"].astype(np.int64), f["x"].astype(np.int64), f["sita"].astype(np.int64)], axis=1)
 
 
-def partner_stats(a, b):
+def partner_stats(a, b, ha=None, hb=None):
     """Fraction of a's keypoints with a partner in b: same octave, layer and orientation bin, position
-    within 0.5 source pixels (octave pixels / size); and the descriptor distances of the exact-position pairs."""
+    within 0.5 source pixels (octave pixels / size); the L2 distances of the unquantised descriptors
+    (clamped histograms ha, hb) of the exact-position pairs; and how many records are identical
+    (position, layer, orientation)."""
     found = 0
+    identical = 0
     l2 = []
     index = {}
     for i, k in enumerate(map(tuple, key(b))):
@@ -43,10 +47,12 @@ def partner_stats(a, b):
             found += 1
         exact = c[d == 0]
         if len(exact):
-            da = a["descr"][i].astype(np.float64) / 512.0
-            db = b["descr"][exact[0]].astype(np.float64) / 512.0
-            l2.append(float(np.sqrt(((da - db) ** 2).sum())))
-    return found / max(len(a), 1), np.asarray(l2)
+            identical += 1
+            if ha is not None:
+                da = ha[i].astype(np.float64)
+                db = hb[exact[0]].astype(np.float64)
+                l2.append(float(np.sqrt(((da - db) ** 2).sum())))
+    return found / max(len(a), 1), np.asarray(l2), identical
 
 
 @pytest.mark.parametrize("case", ["640x480", "1080p", "4k_crop"])
@@ -57,15 +63,17 @@ def test_fast_blur_keypoints_agree_with_oracle(sift, oracle, case):
         img, octaves = sift_amd.blob_image(1920, 1080, seed=12), 4
     else:
         img, octaves = np.ascontiguousarray(sift_amd.blob_image(3840, 2160, seed=1)[700:1600, 1400:2500]), 2
-    f, _ = sift.extract(img, SiftParams(octaves=octaves, blur_mode=1))
-    fo, _ = oracle.extract(img, octaves=octaves)
-    fwd, l2 = partner_stats(fo, f)
-    back, _ = partner_stats(f, fo)
-    print("%s: %d oracle / %d fast keypoints, partner fraction %.5f / %.5f, descriptor L2 of exact pairs: median %.4g max %.4g"
-          % (case, len(fo), len(f), fwd, back, np.median(l2), l2.max()))
+    f, h = sift.extract(img, SiftParams(octaves=octaves, blur_mode=1), want_hist=True)
+    fo, ho = oracle.extract(img, octaves=octaves)
+    fwd, l2, same = partner_stats(fo, f, ho, h)
+    back, _, _ = partner_stats(f, fo)
+    print("%s: %d oracle / %d fast keypoints, %d identical records, without a partner: %d of the oracle's, %d of the "
+          "fast mode's; L2 of the unquantised descriptors of identical records: median %.3g max %.3g"
+          % (case, len(fo), len(f), same, round((1 - fwd) * len(fo)), round((1 - back) * len(f)), np.median(l2), l2.max()))
     assert len(fo) > 500
-    assert fwd >= MIN_PARTNER_FRACTION and back >= MIN_PARTNER_FRACTION
-    assert np.median(l2) == 0.0 and l2.max() <= MAX_DESCR_L2
+    assert 1 - fwd <= MAX_UNPARTNERED and 1 - back <= MAX_UNPARTNERED
+    assert same >= (1 - MAX_UNPARTNERED) * len(fo)
+    assert l2.max() <= MAX_HIST_L2
 
 
 def test_fast_blur_levels_within_a_few_ulps(sift, oracle):

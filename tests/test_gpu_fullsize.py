@@ -98,6 +98,17 @@ def test_1080p_octave0_features_equal_oracle(sift, oracle):
     compare_records(f, h, fo, ho)
 
 
+def test_7680_wide_octave0_features_equal_oracle(sift, oracle):
+    # A 3840-pixel-wide strip, one octave: octave 0 is 7680 x 640, the row length of the 4K frame's
+    # octave 0, so detection, orientation and descriptors run over rows of that width (tile
+    # remapping, buffer offsets, 7680-pixel strides) and the oracle redoes every record.
+    img = np.ascontiguousarray(sift_amd.blob_image(3840, 2160, seed=1)[900:1220])
+    f, h = sift.extract(img, SiftParams(octaves=1), cap=1 << 16, want_hist=True)
+    fo, ho = oracle.extract(img, octaves=1)
+    assert len(fo) > 1500 and (fo["size"] == 2.0).all() and fo["x"].max() > 7000
+    compare_records(f, h, fo, ho)
+
+
 def test_720p_reference_octave_count_features_equal_oracle(sift, oracle):
     # octaves = 0 -> the reference's own count (Sift.cpp:131-139): the deep octaves are a few thousand
     # pixels under kernels longer than the image (whole-row / whole-column passes, their last level

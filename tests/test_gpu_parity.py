@@ -433,12 +433,12 @@ def test_blur_and_resample_random_shapes(sift, oracle):
                 assert np.array_equal(bits(sift.first(img, ratio)), bits(oracle.first(img, ratio))), (case, w, h, ratio)
 
 
-def test_streaming_column_pass_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
+def test_streaming_column_pass_bit_exact_on_ragged_shapes(sift, oracle):
     """The input-stationary column pass (used by itself only on images of 16 Mpixel and more)
     forced onto small and ragged images, with segment lengths that cut columns at awkward rows:
     every tap count it is instantiated for, widths that are not multiples of 64, images shorter
     than the kernel, one-row and one-column images."""
-    monkeypatch.setenv("SIFT_BLUR_STREAM", "1")
+    sift.set_tuning("blur_stream", 1)
     rng = np.random.default_rng(31)
     shapes = [(200, 131), (64, 300), (1, 77), (130, 1), (65, 40), (333, 95)]
     for p, K in ((1.6, 11), (2.2627418, 15), (3.2, 21), (4.5254836, 29), (6.4, 39), (9.0509672, 55)):
@@ -449,19 +449,17 @@ def test_streaming_column_pass_bit_exact_on_ragged_shapes(sift, oracle, monkeypa
                 img[rng.random((h, w)) < 0.3] = 0.0  # exact zeros: +0.0 sums must stay +0.0
             want = bits(oracle.gau_blur(img, p))
             for seg in (None, 1, 7, 37, 1000):
-                if seg is None:
-                    monkeypatch.delenv("SIFT_BLUR_SEG", raising=False)
-                else:
-                    monkeypatch.setenv("SIFT_BLUR_SEG", str(seg))
+                sift.set_tuning("blur_seg", seg or 0)
                 assert np.array_equal(bits(sift.gau_blur(img, p)), want), (K, w, h, seg)
-    monkeypatch.delenv("SIFT_BLUR_SEG", raising=False)
+    sift.set_tuning("blur_seg", 0)
     # negative inputs and negative zeros (the public Gaus::GauBlur takes any float image)
     img = (rng.random((90, 150), dtype=np.float32) - 0.5).astype(np.float32)
     img[::7] = -0.0
     assert np.array_equal(bits(sift.gau_blur(img, 3.2)), bits(oracle.gau_blur(img, 3.2)))
+    sift.set_tuning("blur_stream", -1)
 
 
-def test_streaming_column_pass_on_a_very_wide_image(sift, monkeypatch):
+def test_streaming_column_pass_on_a_very_wide_image(sift):
     """Rows of 2 MB: the segment the streaming column pass would choose (3198 rows) spans more than 2^31
     bytes, which its 32-bit row offsets cannot address, so it must cut shorter segments (975 rows here,
     two per column).  Checked bit for bit against the tiled column pass, which the other tests pin to
@@ -470,16 +468,16 @@ def test_streaming_column_pass_on_a_very_wide_image(sift, monkeypatch):
     rng = np.random.default_rng(41)
     img = np.tile(rng.random((h, 4096), dtype=np.float32), (1, w // 4096))
     img[:, ::4099] = 0.0
-    monkeypatch.setenv("SIFT_BLUR_STREAM", "0")
+    sift.set_tuning("blur_stream", 0)
     want = sift.gau_blur(img, 6.4)
-    monkeypatch.setenv("SIFT_BLUR_STREAM", "1")
+    sift.set_tuning("blur_stream", 1)
     got = sift.gau_blur(img, 6.4)
+    sift.set_tuning("blur_stream", -1)
     assert np.array_equal(bits(got), bits(want))
     del got, want
-    monkeypatch.delenv("SIFT_BLUR_STREAM", raising=False)
 
 
-def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
+def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle):
     """The one-launch form of the blur (row and column pass of a 64 x 64 tile through LDS; by
     itself only used on octaves of 3 Mpixel and more) forced onto small and ragged images: every
     tap count it is instantiated for, sizes that are not multiples of the tile, images smaller
@@ -492,13 +490,13 @@ def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
             img = (rng.random((h, w), dtype=np.float32) - (0.5 if i == 3 else 0.0)).astype(np.float32)
             if i % 2:
                 img[rng.random((h, w)) < 0.3] = 0.0
-            monkeypatch.setenv("SIFT_BLUR_FUSED", "99")
+            sift.set_tuning("blur_fused", 99)
             got0 = bits(sift.gau_blur(img, p))
             got1 = bits(sift.gau_blur(img, p, blur_mode=1))
-            monkeypatch.setenv("SIFT_BLUR_FUSED", "0")
+            sift.set_tuning("blur_fused", 0)
             assert np.array_equal(got0, bits(oracle.gau_blur(img, p))), (K, w, h)
             assert np.array_equal(got1, bits(sift.gau_blur(img, p, blur_mode=1))), (K, w, h)
-    monkeypatch.delenv("SIFT_BLUR_FUSED", raising=False)
+    sift.set_tuning("blur_fused", -1)
     # the launch count shows the form in use: a 2048 x 1600 image takes it for its short kernels
     img = rng.random((1600, 2048), dtype=np.float32)
     sift.profile(True)
@@ -507,8 +505,11 @@ def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle, monkeypatch):
     prof = sift.profile_read(reset=True)
     sift.profile(False)
     assert prof["blur_fused"][1] == 1 and prof["blur_row"][1] == 0 and prof["blur_col"][1] == 0
-    monkeypatch.setenv("SIFT_BLUR_FUSED", "0")
-    assert np.array_equal(bits(out), bits(sift.gau_blur(img, 1.6)))
+    sift.set_tuning("blur_fused", 0)
+    try:
+        assert np.array_equal(bits(out), bits(sift.gau_blur(img, 1.6)))
+    finally:
+        sift.set_tuning("blur_fused", -1)
 
 
 def test_kernel_longer_than_the_image_bit_exact(sift, oracle):

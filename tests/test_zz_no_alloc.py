@@ -39,6 +39,11 @@ def test_noalloc_match_equals_allocating_match_twice():
             (b0, d10, d20), (b1, d11, d21) = run_both(ctx, torch, q, r, ratio, form)
             assert (b0 >= 0).sum() > 0 or nq == 1
             assert np.array_equal(b0, b1) and np.array_equal(d10, d11) and np.array_equal(d20, d21), (nq, nr)
+            if nq == 257:  # and once against the CPU restatement of forceMatchFeat directly
+                from tests.oracle_lib import Oracle
+
+                bo, d1o, d2o = Oracle().match_u8(q, r, ratio, form)
+                assert np.array_equal(b1, bo) and np.array_equal(d11, d1o) and np.array_equal(d21, d2o)
     finally:
         ctx.close()
 

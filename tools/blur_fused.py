@@ -37,9 +37,9 @@ for mode in (0, 1):
     for lvl in [int(x) for x in a.levels.split(",")]:
         p = float(np.float32(1.6) * np.float32(np.sqrt(2.0) ** lvl) * np.float32(a.coef))
         K = len(sift_amd.gau_matrix(p))
-        os.environ["SIFT_BLUR_FUSED"] = "0"
+        ctx.set_tuning("blur_fused", 0)
         ref, t2 = timed(p, mode)
-        os.environ["SIFT_BLUR_FUSED"] = "99"
+        ctx.set_tuning("blur_fused", 99)
         out, t1 = timed(p, mode)
         same = np.array_equal(out.view(np.uint32), ref.view(np.uint32))
         err = float(np.abs(out - ref).max())

@@ -39,14 +39,13 @@ def timed(p):
 for lvl in [int(x) for x in a.levels.split(",")]:
     p = float(np.float32(1.6) * np.float32(np.sqrt(2.0) ** lvl) * np.float32(a.coef))
     K = len(sift_amd.gau_matrix(p))
-    os.environ["SIFT_BLUR_STREAM"] = "0"
-    os.environ.pop("SIFT_BLUR_SEG", None)
+    ctx.set_tuning("blur_stream", 0)
+    ctx.set_tuning("blur_seg", 0)
     ref, row0, col0 = timed(p)
     line = "level %d K=%3d  two-pass: row %.1f us col %.1f us |" % (lvl, K, row0, col0)
-    os.environ["SIFT_BLUR_STREAM"] = "1"
+    ctx.set_tuning("blur_stream", 1)
     for sg in segs:
-        if sg:
-            os.environ["SIFT_BLUR_SEG"] = str(sg)
+        ctx.set_tuning("blur_seg", sg or 0)
         out, row1, col1 = timed(p)
         same = np.array_equal(out.view(np.uint32), ref.view(np.uint32))
         line += " seg %s: row %.1f col %.1f %s |" % (sg or "auto", row1, col1, "same" if same else "DIFFERENT")
