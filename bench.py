@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--pageable-out", action="store_true", help="feature array in ordinary host memory (A/B)")
     ap.add_argument("--no-configs", action="store_true", help="skip the 1080p batch / 8192^2 / reference-octave-count legs")
     ap.add_argument("--no-large", action="store_true", help="skip the 8192^2 frame")
+    ap.add_argument("--batch-frames", type=int, default=1024, help="frames of the 1080p batch over all ranks")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo + SIFT_BENCH_ONE_GPU=1: rehearsal of the multi-rank path on one GPU (collectives on the CPU)")
     args = ap.parse_args()
@@ -425,11 +426,43 @@ def main():
         extras["panorama_separate_calls_ms"] = round((time.perf_counter() - t0) * 1e3, 3)  # (canvas loops on the host not included)
         ctx.profile(False)
 
-    # ---- the other single-GPU configurations of the baseline (rank 0, N = 1; not `value`) ----------
+    # ---- batch of 1024 frames 1920x1080 sharded over the ranks (frame k -> rank k mod N, no collective
+    # on the data path); every rank cycles 64 resident frames through the pipelined batch entry point ----
     configs = None
+    if not args.no_configs:
+        from sift_amd.sharded import frames_of_rank
+        bw, bh, nres, ntotal = 1920, 1080, 64, args.batch_frames
+        mine = len(frames_of_rank(ntotal, world, rank))
+        uniq = [torch.from_numpy(sift_amd.blob_image(bw, bh, seed=1 + rank * 8 + i)).to(dev) for i in range(8)]
+        d_b = torch.stack([uniq[i % 8].reshape(-1) for i in range(nres)]).contiguous()
+        del uniq
+        bcap = 1 << 14
+        bout = ctx.pinned_array(nres * bcap, sift_amd.FEAT_DTYPE).reshape(nres, bcap)
+        bn = np.zeros(nres, np.int32)
+        p4 = SiftParams(octaves=4, blur_mode=args.blur_mode)
+        for _ in range(2):
+            ctx.extract_batch_dev(d_b, bw, bh, nres, p4, bout, bn)
+        barrier()
+        t0 = time.perf_counter()
+        done = 0
+        while done < mine:
+            nb_now = min(nres, mine - done)
+            ctx.extract_batch_dev(d_b, bw, bh, nb_now, p4, bout, bn)
+            done += nb_now
+        t_mine = time.perf_counter() - t0
+        barrier()
+        bt = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            configs = {"batch_1080p": {
+                "workload": "%d frames 1920x1080, 4 octaves, frame k on rank k mod %d, %d resident frames per rank cycled "
+                            "through sift_hip_extract_batch_dev, features to host" % (ntotal, world, nres),
+                "frames": ntotal, "frames_per_s": round(ntotal / bt, 1), "ms_per_frame_per_gpu": round(t_mine / max(mine, 1) * 1e3, 4),
+                "wall_ms": round(bt * 1e3, 2), "features_per_frame": int(bn[0])}}
+        del d_b
+
+    # ---- the other single-GPU configurations of the baseline (rank 0, N = 1; not `value`) ----------
     if rank == 0 and world == 1 and not args.no_configs:
         import ctypes as C
-        configs = {}
         # the reference's own octave count for this frame (getPyramidOctv: 7 at 3840x2160) next to the
         # 4-octave workload that `value` is quoted on
         auto = SiftParams(octaves=0, blur_mode=args.blur_mode)
@@ -442,24 +475,6 @@ def main():
             "workload": "%dx%d frame, octaves = %d (the reference's own count)" % (W, H, sift_amd.pyramid_octaves(W, H)),
             "ms_per_frame": round((time.perf_counter() - t0) / 5 * 1e3, 3), "features": int(na)}
         ctx.extract_dev(d_frame, W, H, prm, out)
-        # 1080p batch: 64 frames resident in HBM through the pipelined batch entry point
-        bw, bh, nb = 1920, 1080, 64
-        f1080 = sift_amd.blob_image(bw, bh, seed=1)
-        d_b = torch.from_numpy(f1080).to(dev).reshape(1, -1).repeat(nb, 1).contiguous()
-        bcap = 1 << 14
-        bout = ctx.pinned_array(nb * bcap, sift_amd.FEAT_DTYPE).reshape(nb, bcap)
-        bn = np.zeros(nb, np.int32)
-        p4 = SiftParams(octaves=4, blur_mode=args.blur_mode)
-        for _ in range(2):
-            ctx.extract_batch_dev(d_b, bw, bh, nb, p4, bout, bn)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctx.extract_batch_dev(d_b, bw, bh, nb, p4, bout, bn)
-        bt = time.perf_counter() - t0
-        configs["batch_1080p"] = {"workload": "%d frames 1920x1080, 4 octaves, resident in HBM, sift_hip_extract_batch_dev" % nb,
-                                  "frames_per_s": round(nb / bt, 1), "ms_per_frame": round(bt / nb * 1e3, 4),
-                                  "features_per_frame": int(bn[0])}
-        del d_b
         # one 8192 x 8192 frame, 6 octaves
         if not args.no_large:
             torch.cuda.empty_cache()
@@ -499,8 +514,68 @@ def main():
         d_d1 = torch.empty(nq_local, dtype=torch.int32, device=dev)
         d_d2 = torch.empty(nq_local, dtype=torch.int32, device=dev)
 
-        def match_step():
-            if world > 1 and args.backend == "nccl":
+        # N > 1 over RCCL: the library's own multi-GPU entry point (sift_hip_match_u8_sharded: one
+        # ncclAllGather of the reference shards on the context's stream, then the matcher) on a
+        # communicator made here with ncclCommInitRank (the id travels through torch.distributed).
+        # The gloo rehearsal (every rank on one GPU, which RCCL refuses) gathers on the CPU instead.
+        import ctypes as C
+        comm, rccl, comm_note, comm_ranks = None, None, None, None
+        want_comm = args.backend == "nccl" and (world > 1 or os.environ.get("SIFT_BENCH_FORCE_COMM") == "1")
+        if want_comm:
+            try:
+                cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"]
+                for name in cand:
+                    try:
+                        rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)  # global: the library looks ncclAllGather up in the process
+                        break
+                    except OSError:
+                        continue
+                if rccl is None:
+                    raise RuntimeError("no librccl found")
+
+                class UniqueId(C.Structure):
+                    _fields_ = [("internal", C.c_byte * 128)]
+
+                uid = UniqueId()
+                if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+                    raise RuntimeError("ncclGetUniqueId failed")
+                t_id = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(coll_dev)
+                if world > 1:
+                    dist.broadcast(t_id, src=0)
+                C.memmove(C.byref(uid), bytes(t_id.cpu().numpy().tobytes()), 128)
+                rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+                rccl.ncclCommInitRank.restype = C.c_int
+                c_comm = C.c_void_p()
+                rc_init = rccl.ncclCommInitRank(C.byref(c_comm), world, uid, rank)
+                if rc_init != 0:
+                    raise RuntimeError("ncclCommInitRank failed with code %d" % rc_init)
+                cnt = C.c_int(0)
+                rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+                rccl.ncclCommCount(c_comm, C.byref(cnt))
+                comm, comm_ranks = c_comm, cnt.value
+            except Exception as e:  # keep the run: fall back to torch's collective + the single-GPU entry point
+                comm_note = "communicator not created (%s): torch.distributed all_gather + sift_hip_match_u8_dev" % e
+            # every rank must take the same path
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm = None
+                comm_note = comm_note or "another rank could not create its communicator: torch.distributed path"
+        lib = ctx.lib
+        vp = C.c_void_p
+        lib.sift_hip_match_u8_sharded.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]
+        lib.sift_hip_match_u8_sharded.restype = C.c_int
+
+        def gather_only():
+            """the exchange step alone (what the library does first)"""
+            if comm is not None:
+                rc_ = lib.sift_hip_match_u8_sharded(ctx.h, comm, world, None, 0, d_rl.data_ptr(), n_all // world, 0.5, 0,
+                                                    None, None, None)
+                if rc_ != 0:
+                    raise RuntimeError("sift_hip_match_u8_sharded (gather only) failed: %d" % rc_)
+                ctx.synchronize()
+            elif world > 1 and args.backend == "nccl":
                 dist.all_gather_into_tensor(d_r, d_rl)   # RCCL over xGMI
                 torch.cuda.current_stream().synchronize()
             elif world > 1:
@@ -511,6 +586,17 @@ def main():
             else:
                 d_r.copy_(d_rl)
                 torch.cuda.current_stream().synchronize()
+
+        def match_step():
+            if comm is not None:
+                rc_ = lib.sift_hip_match_u8_sharded(ctx.h, comm, world, d_q.data_ptr(), nq_local, d_rl.data_ptr(),
+                                                    n_all // world, 0.5, 0, d_best.data_ptr(), d_d1.data_ptr(),
+                                                    d_d2.data_ptr())
+                if rc_ != 0:
+                    raise RuntimeError("sift_hip_match_u8_sharded failed: %d" % rc_)
+                ctx.synchronize()
+                return
+            gather_only()
             ctx.match_u8_dev(d_q, nq_local, d_r, nr_all, 0.5, 0, d_best, d_d1, d_d2)
             ctx.synchronize()
 
@@ -521,6 +607,17 @@ def main():
             match_step()
         barrier()
         mdt = max_over_ranks(time.perf_counter() - t0) / args.match_steps
+        # the exchange step by itself (same buffers, same communicator), outside the timed region
+        gather_only()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.match_steps):
+            gather_only()
+        barrier()
+        agt = max_over_ranks(time.perf_counter() - t0) / args.match_steps
+        if comm is not None:
+            rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            rccl.ncclCommDestroy(comm)
         pairs = float(nq_local) * world * nr_all
         tops = pairs * 256 / mdt / 1e12
         match = {
@@ -531,6 +628,12 @@ def main():
             "nr": nr_all,
             "ms": round(mdt * 1e3, 3),
             "accepted": int((d_best >= 0).sum().item()),
+            "path": ("sift_hip_match_u8_sharded on an ncclCommInitRank communicator of %d ranks" % comm_ranks) if comm_ranks
+                    else (comm_note or ("gloo rehearsal: references gathered on the CPU, sift_hip_match_u8_dev" if world > 1
+                                        else "one rank: sift_hip_match_u8_dev")),
+            "nranks": comm_ranks if comm_ranks else world,
+            "allgather_ms": round(agt * 1e3, 3),
+            "match_ms": round((mdt - agt) * 1e3, 3),
             "roofline": {"bound": "mfma", "achieved": round(tops, 1), "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
                          "frac": round(tops / INT8_DENSE_PEAK_TOPS, 4), "traffic": None},
         }
