@@ -88,8 +88,9 @@ void align_offsets(const Raw& img1, const Raw& img2, const Feature* const* good,
 }
 
 Raw to_raw(const ImgRaw& src) {
-    Raw dst(src.width, src.height);
-    dst.RGB = src;  // the 8-bit copy of Imgraw.hpp:59-82
+    Raw dst;
+    dst.RGB = src;  // the 8-bit copy of Imgraw.hpp:59-82 (moved in: no second allocation of the image's size)
+    dst.resize(src.width, src.height);
     return dst;
 }
 
@@ -122,7 +123,9 @@ void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::ve
               const Feature* const* RANSAC_feat, int RANSAC_num) {
     if (img1.bitCount != 24 || img2.bitCount != 24) throw std::runtime_error("blen2img: both images must be 24-bit RGB");
     if (!RANSAC_feat || RANSAC_num < 2) throw std::runtime_error("blen2img: needs at least two consensus matches");
+    sift_amd::StepTimer tm("blen2img");
     const std::vector<Raw> input = {to_raw(img1), to_raw(img2)};
+    tm.step("8-bit copies");
     const float ft = getFocal(HomogMat, img1.size(), img2.size());
     int dx = 0, dy = 0;
     align_offsets(input[0], input[1], RANSAC_feat, RANSAC_num, ft, &dx, &dy);
@@ -149,5 +152,7 @@ void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::ve
                                               top0, left1, top1, canvas.data(), cols, rows2),
               "sift_hip_panorama_pair");
     }
+    tm.step("sift_hip_panorama_pair");
     dst = ImgRaw(canvas, (uint32_t)cols, (uint32_t)rows2, 24);
+    tm.step("canvas to float");
 }

@@ -3,10 +3,40 @@
 // I/O (the string constructors and bmp()) belongs to the reference's Raw2Img
 // module and is not part of this drop-in.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "imglib.hpp"
+
+namespace sift_amd {
+// fn(begin, end) over [0, n) in contiguous chunks on a few threads (SIFT_HOST_THREADS, default 8,
+// never more than the machine reports): the per-pixel format conversions of whole 4K RGB images
+// that the reference's data model asks for (float <-> 8 bit) are memory-bound loops over
+// tens of millions of elements, far longer than the GPU work between them when run on one core.
+template <typename F>
+inline void parallel_for(size_t n, F fn) {
+    static const unsigned want = [] {
+        const char* e = std::getenv("SIFT_HOST_THREADS");
+        const unsigned t = e ? (unsigned)std::atoi(e) : 8u;
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::max(1u, std::min(t, hw ? hw : 1u));
+    }();
+    const size_t nt = std::min<size_t>(want, (n + (1u << 18) - 1) >> 18);  // at least 256 k elements per thread
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 1; t < nt; t++) th.emplace_back([=] { fn(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    fn((size_t)0, std::min(n, per));
+    for (auto& x : th) x.join();
+}
+}  // namespace sift_amd
 
 float fastAtan2f(float dy, float dx);  // Imgraw.cpp:29-52, degrees in [0,360]
 
@@ -23,7 +53,14 @@ public:
     ImgRaw(const std::vector<unsigned char>& img, uint32_t width, uint32_t height, uint16_t bits)
         : width(width), height(height), bitCount(bits) {
         raw_img.resize(img.size());
-        for (size_t i = 0; i < img.size(); ++i) raw_img[i] = nomal ? (float)(img[i] / ImgRawPixMax) : (float)img[i];
+        // (the 256 possible results of the reference's expression, Imgraw.hpp:30-41, tabulated)
+        float lut[256];
+        for (int v = 0; v < 256; ++v) lut[v] = nomal ? (float)(v / ImgRawPixMax) : (float)v;
+        const unsigned char* src = img.data();
+        float* dst = raw_img.data();
+        sift_amd::parallel_for(img.size(), [=](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) dst[i] = lut[src[i]];
+        });
     }
     ImgRaw(uint32_t width, uint32_t height, uint16_t bits)
         : raw_img((size_t)width * height * (bits / 8)), width(width), height(height), bitCount(bits) {}
@@ -33,8 +70,15 @@ public:
     // 8-bit copy (Imgraw.hpp:59-82): what the stitcher's Raw images are filled from
     operator std::vector<unsigned char>() const {
         std::vector<unsigned char> img(raw_img.size());
-        for (size_t i = 0; i < raw_img.size(); ++i)
-            img[i] = nomal ? (unsigned char)(raw_img[i] * ImgRawPixMax) : (unsigned char)raw_img[i];
+        const float* src = raw_img.data();
+        unsigned char* dst = img.data();
+        const bool scaled = nomal;
+        sift_amd::parallel_for(raw_img.size(), [=](size_t b, size_t e) {
+            if (scaled)
+                for (size_t i = b; i < e; ++i) dst[i] = (unsigned char)(src[i] * ImgRawPixMax);
+            else
+                for (size_t i = b; i < e; ++i) dst[i] = (unsigned char)src[i];
+        });
         return img;
     }
     types& operator[](size_t idx) { return raw_img[idx]; }

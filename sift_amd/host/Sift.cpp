@@ -3,6 +3,7 @@
 #include "Sift.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -53,6 +54,18 @@ ContextUse::~ContextUse() { context_mutex().unlock(); }
 Options& options() {
     static Options o;
     return o;
+}
+
+// SIFT_HOST_TIMING=1: the steps of pyramid() / Check() print their wall time to stderr
+StepTimer::StepTimer(const char* what) : what_(what), t0_(std::chrono::steady_clock::now()) {
+    static const bool on = [] { const char* e = std::getenv("SIFT_HOST_TIMING"); return e && e[0] == '1'; }();
+    on_ = on;
+}
+void StepTimer::step(const char* name) {
+    if (!on_) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[%s] %-28s %8.3f ms\n", what_, name, std::chrono::duration<double, std::milli>(t - t0_).count());
+    t0_ = t;
 }
 
 }  // namespace sift_amd
@@ -172,6 +185,7 @@ void Sift::pyramid() {
     if (raw_img.bitCount != 8 && raw_img.bitCount != 24) throw Size_error("Sift::pyramid: bitCount must be 8 or 24");
     if (raw_img.raw_img.size() < (size_t)raw_img.width * raw_img.height * (raw_img.bitCount / 8))
         throw Size_error("Sift::pyramid: image buffer smaller than width*height");
+    sift_amd::StepTimer tm("pyramid");
     sift_amd::ContextUse use;
     sift_hip_ctx* ctx = use.ctx;
     sift_hip_params prm;
@@ -205,6 +219,7 @@ void Sift::pyramid() {
         check(ctx, rc, "sift_hip_extract");
         break;
     }
+    tm.step("sift_hip_extract");
     // refined positions (matrix.hpp:188-189); without refinement img_pt stays zero as in the reference
     std::vector<float> sub;
     if (prm.subpixel && n > 0) {
@@ -235,6 +250,7 @@ void Sift::pyramid() {
     FeatStart = arr;
     FeatEnd = arr + (n > 0 ? n - 1 : 0);
     feaNum = (size_t)n;
+    tm.step("Feature[] fill");
 }
 
 // ---- Stitching -------------------------------------------------------------------------
@@ -286,7 +302,9 @@ size_t Stitching::Match(float matchTh) {
 Stitching::~Stitching() { delete[] RANSAC_feat; }
 
 void Stitching::Check(float matchTh) {
+    sift_amd::StepTimer tm("Check");
     Match(matchTh);
+    tm.step("Match");
     // Sift.cpp:681-684
     delete[] RANSAC_feat;
     RANSAC_feat = nullptr;
@@ -319,9 +337,11 @@ void Stitching::Check(float matchTh) {
             RANSAC_num = n_in;
         }
     }
+    tm.step("RANSAC");
     // blen2img (Sift.cpp:697) for colour pairs with a model; the reference then writes the panorama to
     // a BMP file, which is left to the caller here
     Panorama = ImgRaw();
     if (HomogMat.size() == 9 && RANSAC_num >= 2 && img1.bitCount == 24 && img2.bitCount == 24)
         blen2img(img1, img2, Panorama, HomogMat, RANSAC_feat, RANSAC_num);
+    tm.step("blen2img");
 }

@@ -4,6 +4,7 @@
 // (stitch/Blend.cpp:898) keep compiling against it.  Sift::pyramid() and the
 // matcher inside Stitching::Check() run on the GPU through include/sift_hip.h.
 #pragma once
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -55,6 +56,17 @@ struct Options {
     int ransac_on_gpu = 1; // Stitching::Check: 1 = sift_hip_ransac_homog, 0 = ransac_xform on the CPU (same result)
 };
 Options& options();
+// Wall time of the steps of a host call, printed to stderr when SIFT_HOST_TIMING=1.
+class StepTimer {
+public:
+    explicit StepTimer(const char* what);
+    void step(const char* name);
+
+private:
+    const char* what_;
+    std::chrono::steady_clock::time_point t0_;
+    bool on_;
+};
 }  // namespace sift_amd
 
 class Size_error : public std::runtime_error {

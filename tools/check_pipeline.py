@@ -35,6 +35,8 @@ with tempfile.TemporaryDirectory() as d:
                          text=True, timeout=600)
     if res.returncode:
         sys.exit(res.stderr)
+    if os.environ.get("SIFT_HOST_TIMING") == "1":
+        sys.stderr.write(res.stderr)  # per-step wall times of the host classes
     info = json.loads(res.stdout.strip().splitlines()[-1])
 print("%dx%d RGB pair: two pyramids %.2f ms, Check %.2f ms; %d / %d features, %d matches, consensus %d, panorama %s" % (
     w, h, info["ms_two_pyramids"], info["ms_check"], info["n1"], info["n2"], info["matched"], info["ransac_num"], info["pano"]))
