@@ -306,7 +306,9 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     const Plan& pl = ctx->plan;
     const int noct = (int)pl.oct.size();
     if (noct > G_MAX_OCT) return SIFT_HIP_ERR_LIMIT;
-    if ((rc = ensure(ctx, ctx->gcounters, G_SLOTS * sizeof(int)))) return rc;
+    // (page-locked host memory that the kernels write through the bus: once a stream has been joined its
+    // counters are simply there, without a copy and a second wait)
+    if ((rc = ensure_pinned(ctx, ctx->gcounters, G_SLOTS * sizeof(int)))) return rc;
     // all allocation first: ensure() may synchronise, which must not happen between launches
     for (int oi = 0; oi < noct; oi++) {
         OctWs* ws;
@@ -340,9 +342,15 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
     // With profiling on (or SIFT_HIP_SERIAL=1) everything runs on the main stream, so that
     // kernel durations are not inflated by another octave's kernels sharing the GPU.
     const bool serial = ctx->profiling || ctx->force_serial || noct < 2;
+    // Where octave 3 goes (tune.o3_place): 0 = behind octave 2 on the second side stream, 1 = in front of
+    // octave 1 on the first, 2 = behind octave 1, 3 = in front of octave 2, 4 = on the deep-octave stream.
+    const int o3_place = (!serial && ctx->n_side >= 2 && noct > 3 && ctx->tune.interleave != 0 && !ctx->pipelined)
+                             ? ctx->tune.o3_place : 0;
     auto stream_of = [&](int oi) -> hipStream_t {
         if (serial || oi == 0) return ctx->stream;
         if (oi == 1 || ctx->n_side < 2) return ctx->side_stream;
+        if (oi == 3 && (o3_place == 1 || o3_place == 2)) return ctx->side_stream;
+        if (oi == 3 && o3_place == 4) return ctx->side_stream3;
         return oi < 4 ? ctx->side_stream2 : ctx->side_stream3;
     };
     if (frame_state == 1 && !serial) hipEventRecord(ctx->ev_start, ctx->stream);
@@ -398,7 +406,10 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         // are what ends the frame, so they should start first, not 0.2 ms in).
         // the first octave of each stream: 0, 1, 2 and (frames with more than four octaves) 4
         int heads[4] = {0, 1, 2, 4};
-        const int nhead = noct > 4 ? 4 : 3;
+        const int nhead = (noct > 4 || o3_place == 4) ? 4 : 3;
+        if (o3_place == 1) heads[1] = 3;  // octave 3 leads the first side stream, octave 1 follows it
+        if (o3_place == 3) heads[2] = 3;  // octave 3 leads the second side stream, octave 2 follows it
+        if (o3_place == 4) heads[3] = 3;  // octave 3 leads the deep stream, octaves 4, 5, ... follow it
         int nlev[4];
         for (int k = 0; k < nhead; k++) {
             const int oi = heads[k];
@@ -420,8 +431,8 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
                     return rc;
         for (int k = nhead - 1; k >= 0; k--)
             if ((rc = enqueue_part(heads[k], 1))) return rc;
-        // the followers on the two deep streams (octave 3; octaves 5, 6, ...) in turn
-        int a = 3, b = 5;
+        // the followers (the octave that shares a stream with a leader; octaves 5, 6, ... on the deep stream) in turn
+        int a = o3_place == 1 ? 1 : o3_place == 3 ? 2 : o3_place == 4 ? 4 : 3, b = o3_place == 4 ? 4 : 5;
         while (a < 4 || b < noct) {
             if (a < 4 && a < noct) {
                 if ((rc = enqueue_part(a, 0))) return rc;
@@ -477,10 +488,8 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
         const bool plain = !hist && ctx->plan.prm.subpixel == 0 && st == ctx->stream &&
                            (size_t)ctx->plan.oct[0].W * ctx->plan.oct[0].H >= ((size_t)16 << 20);
         if (plain) {
-            if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int),
-                                            hipMemcpyDeviceToHost, st), "read counters") ||
-                !hip_ok(ctx, hipStreamSynchronize(st), "extract (octave 0)"))
-                return SIFT_HIP_ERR_HIP;
+            if (!hip_ok(ctx, hipStreamSynchronize(st), "extract (octave 0)")) return SIFT_HIP_ERR_HIP;
+            std::memcpy(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int));
             int found0 = ctx->h_counters[G_OCT_CAND];
             if (ctx->lanes[0].lazy_top) found0 = std::max(found0, ctx->h_counters[G_OCT_CAND_TOP]);
             if (found0 <= ctx->cand_cap) {
@@ -495,10 +504,8 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
             !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream3), "extract (third side stream)"))
             return SIFT_HIP_ERR_HIP;
     }
-    if (!hip_ok(ctx, hipMemcpyAsync(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int), hipMemcpyDeviceToHost,
-                                    st), "read counters"))
-        return SIFT_HIP_ERR_HIP;
     if (!hip_ok(ctx, hipStreamSynchronize(st), "extract")) return SIFT_HIP_ERR_HIP;
+    std::memcpy(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int));
     *cand_overflow = 0;
     for (int oi = 0; oi < (int)ctx->plan.oct.size(); oi++) {
         int found = ctx->h_counters[G_OCT_CAND + oi];
@@ -699,7 +706,7 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("SIFT_HIP_NSIDE")) ctx->n_side = (e[0] == '1') ? 1 : 2;
     // launch-shape switches: looked up here once, never on a launch path
-    for (const char* key : {"blur_seg", "blur_stream", "blur_fused", "match_nb", "interleave", "multi_octave"}) {
+    for (const char* key : {"blur_seg", "blur_stream", "blur_fused", "match_nb", "interleave", "multi_octave", "o3_place"}) {
         std::string name = key == std::string("interleave") ? "SIFT_HIP_INTERLEAVE"
                          : key == std::string("match_nb")   ? "SIFT_MATCH_NB"
                          : key == std::string("multi_octave") ? "SIFT_HIP_MULTI_OCTAVE"
@@ -756,7 +763,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
             if (b->p) hipFree(b->p);
     }
     DevBuf* bufs[] = {&ctx->in_img, &ctx->in_rgb, &ctx->tmp, &ctx->table, &ctx->layer_consts,
-                      &ctx->gcounters, &ctx->gcounters_alt, &ctx->gathered, &ctx->gather_in, &ctx->gather_pad, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
+                      &ctx->gathered, &ctx->gather_in, &ctx->gather_pad, &ctx->qi8, &ctx->ri8, &ctx->qnorm, &ctx->rconst, &ctx->best, &ctx->d1, &ctx->d2,
                       &ctx->io_a, &ctx->io_b, &ctx->frame2, &ctx->dog_all,
                       &ctx->ransac.blk, &ctx->ransac.pairs, &ctx->ransac.src, &ctx->ransac.flags, &ctx->ransac.samples,
                       &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best,
@@ -767,6 +774,8 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
     if (ctx->h_feat.p) hipHostFree(ctx->h_feat.p);
     if (ctx->h_hist.p) hipHostFree(ctx->h_hist.p);
+    if (ctx->gcounters.p) hipHostFree(ctx->gcounters.p);
+    if (ctx->gcounters_alt.p) hipHostFree(ctx->gcounters_alt.p);
     if (ctx->h_counters) hipHostFree(ctx->h_counters);
     if (ctx->h_counters_alt) hipHostFree(ctx->h_counters_alt);
     for (hipEvent_t e : ctx->ev_frame) if (e) hipEventDestroy(e);
@@ -820,6 +829,7 @@ int sift_hip_set_tuning(sift_hip_ctx* ctx, const char* key, int value) {
     else if (k == "match_nb") { if (value != 0 && value != 2 && value != 4) return SIFT_HIP_ERR_ARG; t.match_nb = value; }
     else if (k == "interleave") t.interleave = value != 0;
     else if (k == "multi_octave") t.multi_octave = value != 0;
+    else if (k == "o3_place") { if (value < 0 || value > 4) return SIFT_HIP_ERR_ARG; t.o3_place = value; }
     else return SIFT_HIP_ERR_ARG;
     return SIFT_HIP_OK;
 }

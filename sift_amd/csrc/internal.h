@@ -80,6 +80,7 @@ struct Tuning {
     int match_nb = 0;      // matcher: 32-query blocks per wave, 0 = by query count, else 2 or 4
     int interleave = 1;    // single frames: pyramids of the streams' first octaves enqueued level by level in turn
     int multi_octave = 1;  // the small octaves' blur passes of one level share a launch
+    int o3_place = 3;      // single frames of four octaves and more: where octave 3 runs (see enqueue_extract)
 };
 
 struct Plan {
