@@ -250,15 +250,34 @@ def main():
         bigpx = [p_ for p_ in px if p_ >= (3 << 20)]
         alg_l = 8.0 * sum(bigpx) / max(len(bigpx), 1)
         avg = pf[domf][0] / max(pf[domf][1], 1)
+        # measured traffic of that class from the float-mode counter passes (same hash rule as above)
+        traffic_f, traffic_f_note, stage_traffic = None, None, None
+        ffiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_fast.json")))
+        if ffiles and (W, H, args.octaves) == (3840, 2160, 4):
+            fj = json.load(open(ffiles[-1]))
+            if fj.get("kernel_source_sha256") == src_hash:
+                wantf = {"blur_col": ("blur_col_kernel<float, 8>",), "blur_row": ("blur_row_kernel<float, 8>",),
+                         "blur_fused": ("blur_fused_kernel<float",)}[domf]
+                kk = [v for k, v in fj["kernels"].items() if k.startswith(wantf)]
+                nl = sum(v["launches_per_frame"] for v in kk)
+                if kk and nl:
+                    traffic_f = round(sum(v["read"] + v["write"] for v in kk) / nl)
+                    traffic_f_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, blur_mode 1), per launch of the " \
+                                     "class; profiles/" + os.path.basename(ffiles[-1])
+                    stage_traffic = sum(v["read"] + v["write"] for k, v in fj["kernels"].items() if k.startswith("blur_"))
+            else:
+                traffic_f_note = "profiles/%s was measured on other kernel sources: not reported" % os.path.basename(ffiles[-1])
         roofline_fast = {
             "blur_mode": 1, "bound": "hbm", "kernel": domf + " class (dominant by total time)",
             "achieved": round(alg_l / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(alg_l / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(alg_l / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_f,
+            "traffic_source": traffic_f_note,
             "algorithmic_bytes_per_launch": round(alg_l), "avg_launch_ms": round(avg, 5),
             "pyramid_stage": {"launches_per_frame": launches, "algorithmic_bytes_per_frame": alg,
                               "ms_per_frame": round(t_fast, 4),
                               "achieved_GBps": round(alg / (t_fast * 1e-3) / 1e9, 1),
-                              "frac": round(alg / (t_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                              "frac": round(alg / (t_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "traffic_blur_kernels_per_frame": stage_traffic},
             "stage_ms_per_frame": {k: round(v[0] / 3, 4) for k, v in pf.items() if v[1]},
         }
 
@@ -620,6 +639,23 @@ def main():
             rccl.ncclCommDestroy(comm)
         pairs = float(nq_local) * world * nr_all
         tops = pairs * 256 / mdt / 1e12
+        # matrix-pipe counters of the matcher from the rocprofv3 pass kept under profiles/ (they cannot be
+        # collected inside this process); quoted only while that pass was taken on this match.hip
+        match_counters = None
+        if rank == 0:
+            import glob
+            import hashlib
+            mfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_match_pmc.json")))
+            if mfiles:
+                mj = json.load(open(mfiles[-1]))
+                mh = hashlib.sha256(open(os.path.join(ROOT, "sift_amd", "csrc", "match.hip"), "rb").read()).hexdigest()
+                if mj.get("kernel_source_sha256") == mh:
+                    dd = mj["derived"]
+                    match_counters = {"source": "profiles/" + os.path.basename(mfiles[-1]), "workload": mj["workload"],
+                                      "mfma_pipe_busy_fraction": dd.get("mfma_pipe_busy_fraction"),
+                                      "clock_GHz_under_load": dd.get("clock_GHz_under_load"),
+                                      "executed_over_algorithmic_ops": dd.get("executed_over_algorithmic"),
+                                      "lds_bank_conflict_fraction_of_active": dd.get("lds_bank_conflict_fraction_of_active")}
         match = {
             "metric": "descriptor-match Gpairs/s (exact NN + ratio test, int8 MFMA)",
             "value": round(pairs / mdt / 1e9, 1),
@@ -635,7 +671,7 @@ def main():
             "allgather_ms": round(agt * 1e3, 3),
             "match_ms": round((mdt - agt) * 1e3, 3),
             "roofline": {"bound": "mfma", "achieved": round(tops, 1), "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
-                         "frac": round(tops / INT8_DENSE_PEAK_TOPS, 4), "traffic": None},
+                         "frac": round(tops / INT8_DENSE_PEAK_TOPS, 4), "traffic": None, "counters": match_counters},
         }
 
     # ---- CPU baseline: the oracle (a port of the reference's algorithm), one thread ----

@@ -238,6 +238,28 @@ def test_lazy_top_level_equals_full_level(sift):
     assert f.tobytes() == f2.tobytes() and np.array_equal(h, h2)
 
 
+def test_octave_placement_on_the_streams_changes_nothing(sift, oracle):
+    """Which side stream octave 3 runs on, and whether it leads or follows there, is a scheduling
+    choice (sift_hip_set_tuning "o3_place"): every placement must return the same bytes, frames of
+    exactly four octaves and frames with deeper ones alike, and those bytes are the oracle's."""
+    img = sift_amd.blob_image(800, 600, seed=21)
+    fo, _ = oracle.extract(img, octaves=4)
+    try:
+        for octaves in (4, 0):
+            want = None
+            for place in (3, 0, 1, 2, 4, 3):
+                sift.set_tuning("o3_place", place)
+                for _ in range(2):
+                    f, _ = sift.extract(img, SiftParams(octaves=octaves))
+                    want = f.tobytes() if want is None else want
+                    assert f.tobytes() == want, (octaves, place)
+            if octaves == 4:
+                assert len(f) == len(fo) and all(np.array_equal(f[k], fo[k]) for k in ("x", "y", "kai", "sita", "size"))
+    finally:
+        sift.set_tuning("o3_place", 3)
+    assert sift.lib.sift_hip_set_tuning(sift.h, b"o3_place", 5) == sift_amd.capi.ERR_ARG
+
+
 # ---- against the committed golden vectors (reference object code outputs) ---------------
 def _golden(name):
     import os
