@@ -289,6 +289,14 @@ int sift_hip_multiband_blend_dev(sift_hip_ctx* ctx, uint8_t* d_l_rgb, int lw, in
 int sift_hip_panorama_pair(sift_hip_ctx* ctx, const uint8_t* img1_rgb, int w1, int h1, const uint8_t* img2_rgb, int w2,
                            int h2, float focal, int dx, int blend_dy, int top0, int left1, int top1, uint8_t* canvas_rgb,
                            int cols, int rows);
+/* The same with the two images as ImgRaw holds them (Sift/Imgraw.hpp:30-41): interleaved float RGB in host
+ * memory, samples in [0,1] when `normalised` is non-zero and in [0,255] otherwise.  The 8-bit copies blen2img
+ * makes first (Blend.cpp:907-916 through Imgraw.hpp:59-82: (unsigned char)(v * 255.0), the product in double,
+ * truncated) are made on the device after the upload, so the host never walks the pixels.  Results equal
+ * sift_hip_panorama_pair on the 8-bit copies. */
+int sift_hip_panorama_pair_f32(sift_hip_ctx* ctx, const float* img1_rgb, int w1, int h1, const float* img2_rgb, int w2,
+                               int h2, int normalised, float focal, int dx, int blend_dy, int top0, int left1, int top1,
+                               uint8_t* canvas_rgb, int cols, int rows);
 
 /* ---- measurement ------------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by HIP events on the

@@ -132,6 +132,8 @@ def load_library() -> C.CDLL:
         "sift_hip_multiband_blend_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "sift_hip_panorama_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                              C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
+        "sift_hip_panorama_pair_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
         "sift_hip_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
@@ -415,6 +417,17 @@ class SiftHip:
         self._check(self.lib.sift_hip_panorama_pair(self.h, _ptr(img1), img1.shape[1], img1.shape[0], _ptr(img2), img2.shape[1],
                                                     img2.shape[0], focal, dx, blend_dy, top0, left1, top1, _ptr(canvas), cols,
                                                     rows))
+        return canvas
+
+    def panorama_pair_f32(self, img1: np.ndarray, img2: np.ndarray, normalised: bool, focal: float, dx: int, blend_dy: int,
+                          top0: int, left1: int, top1: int, cols: int, rows: int) -> np.ndarray:
+        """panorama_pair on float images as ImgRaw holds them; their 8-bit copies (Imgraw.hpp:59-82) are made on the device."""
+        for a in (img1, img2):
+            assert a.dtype == np.float32 and a.ndim == 3 and a.shape[2] == 3 and a.flags.c_contiguous
+        canvas = np.empty((rows, cols, 3), np.uint8)
+        self._check(self.lib.sift_hip_panorama_pair_f32(self.h, _ptr(img1), img1.shape[1], img1.shape[0], _ptr(img2),
+                                                        img2.shape[1], img2.shape[0], 1 if normalised else 0, focal, dx,
+                                                        blend_dy, top0, left1, top1, _ptr(canvas), cols, rows))
         return canvas
 
     # ---- measurement ----------------------------------------------------------------

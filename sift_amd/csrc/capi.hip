@@ -767,7 +767,7 @@ int sift_hip_destroy(sift_hip_ctx* ctx) {
                       &ctx->ransac.blk, &ctx->ransac.pairs, &ctx->ransac.src, &ctx->ransac.flags, &ctx->ransac.samples,
                       &ctx->ransac.models, &ctx->ransac.counts, &ctx->ransac.qf, &ctx->ransac.rf, &ctx->ransac.best,
                       &ctx->warp_src, &ctx->warp_dst, &ctx->warp_edges, &ctx->blend_ws, &ctx->blend_l, &ctx->blend_r,
-                      &ctx->pano_src, &ctx->pano_canvas};
+                      &ctx->pano_src, &ctx->pano_canvas, &ctx->pano_f32};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
@@ -1301,6 +1301,36 @@ int sift_hip_multiband_blend(sift_hip_ctx* ctx, uint8_t* l_rgb, int lw, int lh, 
     return check_async(ctx, "multiband_blend");
 }
 
+// Shared part of the two panorama entry points: projections of the two 8-bit images already on the device, blend,
+// canvas, download.
+static int panorama_from_device(sift_hip_ctx* ctx, const uint8_t* d_src1, int w1, int h1, const uint8_t* d_src2, int w2, int h2,
+                                float focal, int dx, int blend_dy, int top0, int left1, int top1, uint8_t* canvas_rgb, int cols,
+                                int rows) {
+    hipStream_t st = ctx->stream;
+    // warping (Blend.cpp:974): both projections stay on the device
+    launch_warp_cylinder(ctx, st, d_src1, w1, h1, focal, (uint8_t*)ctx->blend_l.p, nullptr, nullptr);
+    launch_warp_cylinder(ctx, st, d_src2, w2, h2, focal, (uint8_t*)ctx->blend_r.p, nullptr, nullptr);
+    // multiBandBlend (Blend.cpp:994-996) on the projections, then the canvas (Blend.cpp:1010-1031)
+    const int rc = sift_hip_multiband_blend_dev(ctx, (uint8_t*)ctx->blend_l.p, w1, h1, (uint8_t*)ctx->blend_r.p, w2, h2, dx, blend_dy);
+    if (rc) return rc;
+    launch_compose_pair(ctx, st, (const uint8_t*)ctx->blend_l.p, w1, h1, (const uint8_t*)ctx->blend_r.p, w2, h2, top0, left1,
+                        top1, (uint8_t*)ctx->pano_canvas.p, cols, rows);
+    if (!hip_ok(ctx, hipMemcpyAsync(canvas_rgb, ctx->pano_canvas.p, (size_t)cols * rows * 3, hipMemcpyDeviceToHost, st),
+                "download canvas") ||
+        !hip_ok(ctx, hipStreamSynchronize(st), "panorama_pair"))
+        return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "panorama_pair");
+}
+
+static int panorama_buffers(sift_hip_ctx* ctx, size_t b1, size_t b2, size_t bc, size_t* off2) {
+    *off2 = (b1 + 255) / 256 * 256;  // the second image starts on an aligned address of the shared buffer
+    int rc;
+    if ((rc = ensure(ctx, ctx->pano_src, *off2 + b2))) return rc;
+    if ((rc = ensure(ctx, ctx->blend_l, b1))) return rc;
+    if ((rc = ensure(ctx, ctx->blend_r, b2))) return rc;
+    return ensure(ctx, ctx->pano_canvas, bc);
+}
+
 int sift_hip_panorama_pair(sift_hip_ctx* ctx, const uint8_t* img1_rgb, int w1, int h1, const uint8_t* img2_rgb, int w2,
                            int h2, float focal, int dx, int blend_dy, int top0, int left1, int top1, uint8_t* canvas_rgb,
                            int cols, int rows) {
@@ -1308,30 +1338,44 @@ int sift_hip_panorama_pair(sift_hip_ctx* ctx, const uint8_t* img1_rgb, int w1, i
         warp_size_bad(cols, rows))
         return SIFT_HIP_ERR_ARG;
     const size_t b1 = (size_t)w1 * h1 * 3, b2 = (size_t)w2 * h2 * 3, bc = (size_t)cols * rows * 3;
+    size_t off2;
     int rc;
-    const size_t off2 = (b1 + 255) / 256 * 256;  // the second image starts on an aligned address of the shared buffer
-    if ((rc = ensure(ctx, ctx->pano_src, off2 + b2))) return rc;
-    if ((rc = ensure(ctx, ctx->blend_l, b1))) return rc;
-    if ((rc = ensure(ctx, ctx->blend_r, b2))) return rc;
-    if ((rc = ensure(ctx, ctx->pano_canvas, bc))) return rc;
+    if ((rc = panorama_buffers(ctx, b1, b2, bc, &off2))) return rc;
     uint8_t* d_src1 = (uint8_t*)ctx->pano_src.p;
     uint8_t* d_src2 = d_src1 + off2;
     hipStream_t st = ctx->stream;
     if (!hip_ok(ctx, hipMemcpyAsync(d_src1, img1_rgb, b1, hipMemcpyHostToDevice, st), "upload image 1") ||
         !hip_ok(ctx, hipMemcpyAsync(d_src2, img2_rgb, b2, hipMemcpyHostToDevice, st), "upload image 2"))
         return SIFT_HIP_ERR_HIP;
-    // warping (Blend.cpp:974): both projections stay on the device
-    launch_warp_cylinder(ctx, st, d_src1, w1, h1, focal, (uint8_t*)ctx->blend_l.p, nullptr, nullptr);
-    launch_warp_cylinder(ctx, st, d_src2, w2, h2, focal, (uint8_t*)ctx->blend_r.p, nullptr, nullptr);
-    // multiBandBlend (Blend.cpp:994-996) on the projections, then the canvas (Blend.cpp:1010-1031)
-    rc = sift_hip_multiband_blend_dev(ctx, (uint8_t*)ctx->blend_l.p, w1, h1, (uint8_t*)ctx->blend_r.p, w2, h2, dx, blend_dy);
-    if (rc) return rc;
-    launch_compose_pair(ctx, st, (const uint8_t*)ctx->blend_l.p, w1, h1, (const uint8_t*)ctx->blend_r.p, w2, h2, top0, left1,
-                        top1, (uint8_t*)ctx->pano_canvas.p, cols, rows);
-    if (!hip_ok(ctx, hipMemcpyAsync(canvas_rgb, ctx->pano_canvas.p, bc, hipMemcpyDeviceToHost, st), "download canvas") ||
-        !hip_ok(ctx, hipStreamSynchronize(st), "panorama_pair"))
+    return panorama_from_device(ctx, d_src1, w1, h1, d_src2, w2, h2, focal, dx, blend_dy, top0, left1, top1, canvas_rgb, cols,
+                                rows);
+}
+
+int sift_hip_panorama_pair_f32(sift_hip_ctx* ctx, const float* img1_rgb, int w1, int h1, const float* img2_rgb, int w2, int h2,
+                               int normalised, float focal, int dx, int blend_dy, int top0, int left1, int top1,
+                               uint8_t* canvas_rgb, int cols, int rows) {
+    if (bad_ctx(ctx) || !img1_rgb || !img2_rgb || !canvas_rgb || !(focal > 0.f) || blend_args_bad(w1, h1, w2, h2, dx, blend_dy) ||
+        warp_size_bad(cols, rows))
+        return SIFT_HIP_ERR_ARG;
+    const size_t b1 = (size_t)w1 * h1 * 3, b2 = (size_t)w2 * h2 * 3, bc = (size_t)cols * rows * 3;
+    size_t off2;
+    int rc;
+    if ((rc = panorama_buffers(ctx, b1, b2, bc, &off2))) return rc;
+    // one staging buffer for the float samples of either image: the stream orders the second upload behind the
+    // first conversion
+    if ((rc = ensure(ctx, ctx->pano_f32, std::max(b1, b2) * sizeof(float)))) return rc;
+    uint8_t* d_src1 = (uint8_t*)ctx->pano_src.p;
+    uint8_t* d_src2 = d_src1 + off2;
+    float* d_f = (float*)ctx->pano_f32.p;
+    hipStream_t st = ctx->stream;
+    if (!hip_ok(ctx, hipMemcpyAsync(d_f, img1_rgb, b1 * sizeof(float), hipMemcpyHostToDevice, st), "upload image 1"))
         return SIFT_HIP_ERR_HIP;
-    return check_async(ctx, "panorama_pair");
+    launch_float_to_u8(ctx, st, d_f, b1, normalised != 0, d_src1);
+    if (!hip_ok(ctx, hipMemcpyAsync(d_f, img2_rgb, b2 * sizeof(float), hipMemcpyHostToDevice, st), "upload image 2"))
+        return SIFT_HIP_ERR_HIP;
+    launch_float_to_u8(ctx, st, d_f, b2, normalised != 0, d_src2);
+    return panorama_from_device(ctx, d_src1, w1, h1, d_src2, w2, h2, focal, dx, blend_dy, top0, left1, top1, canvas_rgb, cols,
+                                rows);
 }
 
 static int ransac_args_bad(sift_hip_ctx* ctx, const void* q, int nq, const void* r, int nr, const void* best, int m,

@@ -122,6 +122,7 @@ struct sift_hip_ctx {
     sifthip::RansacWs ransac;
     sifthip::DevBuf warp_src, warp_dst, warp_edges;
     sifthip::DevBuf pano_src, pano_canvas;       // sift_hip_panorama_pair: the two uploaded images; the canvas
+    sifthip::DevBuf pano_f32;                    // sift_hip_panorama_pair_f32: float samples of one image on their way to 8 bits
     sifthip::DevBuf blend_ws, blend_l, blend_r;  // multiBandBlend: pyramids and scratch; device copies of host images
     hipEvent_t ev_frame[2] = {nullptr, nullptr};  // end of a batch frame's work on `stream` ...
     hipEvent_t ev_side[2] = {nullptr, nullptr};   // ... on `side_stream`
@@ -209,6 +210,8 @@ void launch_warp_cylinder(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_sr
 int run_multiband_blend(sift_hip_ctx* ctx, uint8_t* d_l, int lw, int lh, uint8_t* d_r, int rw, int rh, int dx, int dy);
 void launch_compose_pair(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_a, int ca, int ra, const uint8_t* d_b, int cb,
                          int rb, int top0, int left1, int top1, uint8_t* d_canvas, int cols, int rows);
+// n float samples to 8 bits the way ImgRaw's 8-bit copy does (Imgraw.hpp:59-82); d_dst 4-byte aligned
+void launch_float_to_u8(sift_hip_ctx* ctx, hipStream_t st, const float* d_src, size_t n, bool normalised, uint8_t* d_dst);
 // ransac.hip; features and best in device memory, outputs in host memory
 int run_ransac(sift_hip_ctx* ctx, const sift_hip_feat* d_q, int nq, const sift_hip_feat* d_r, int nr,
                const int32_t* d_best, int m, float p_badxform, float err_tol, unsigned seed, float* H9,

@@ -196,4 +196,33 @@ void launch_compose_pair(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_a, 
                                                                                d_canvas, cols, rows);
 }
 
+// ---- ImgRaw's 8-bit copy (Imgraw.hpp:59-82) ---------------------------------------------
+// (unsigned char)(v * 255.0) for images that hold [0,1] samples, (unsigned char)v otherwise: the product in double,
+// truncated towards zero, its low byte kept (what the conversion compiles to on x86 for values an int holds).  Four
+// samples per thread.
+__global__ __launch_bounds__(256) void float_to_u8_kernel(const float* __restrict__ src, size_t n, int normalised,
+                                                          uint8_t* __restrict__ dst) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const double scale = normalised ? 255.0 : 1.0;
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        uchar4 o;
+        o.x = (uint8_t)(int)((double)v.x * scale);
+        o.y = (uint8_t)(int)((double)v.y * scale);
+        o.z = (uint8_t)(int)((double)v.z * scale);
+        o.w = (uint8_t)(int)((double)v.w * scale);
+        *reinterpret_cast<uchar4*>(dst + i) = o;
+    } else {
+        for (size_t k = i; k < n; ++k) dst[k] = (uint8_t)(int)((double)src[k] * scale);
+    }
+}
+
+void launch_float_to_u8(sift_hip_ctx* ctx, hipStream_t st, const float* d_src, size_t n, bool normalised, uint8_t* d_dst) {
+    if (n == 0) return;
+    ProfScope ps(ctx, SIFT_HIP_K_WARP, st);
+    const size_t threads = (n + 3) / 4;
+    float_to_u8_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(d_src, n, normalised ? 1 : 0, d_dst);
+}
+
 }  // namespace sifthip

@@ -64,7 +64,14 @@ void cylinder_pixel(float px, float py, float mid_x, float mid_y, float fl, floa
 
 // alignMatch (Blend.cpp:745-825): mean offset of the second image against the first over the
 // consensus matches (all but the last, as the reference loops), then its parity fix-ups.
-void align_offsets(const Raw& img1, const Raw& img2, const Feature* const* good, int n, float fl, int* dx, int* dy) {
+// Columns and rows of an image, which is all alignMatch reads of its two Raw arguments.
+struct Extent {
+    int col, row;
+    int getCol() const { return col; }
+    int getRow() const { return row; }
+};
+
+void align_offsets(const Extent& img1, const Extent& img2, const Feature* const* good, int n, float fl, int* dx, int* dy) {
     const float mid_x1 = (float)img1.getCol() / 2.f, mid_x2 = (float)img2.getCol() / 2.f;
     const float mid_y1 = (float)img1.getRow() / 2.f, mid_y2 = (float)img2.getRow() / 2.f;
     const float fl_sq = std::pow(fl, 2);
@@ -85,13 +92,6 @@ void align_offsets(const Raw& img1, const Raw& img2, const Feature* const* good,
     else if (oy % 2 == 1) oy += 1;
     *dx = ox;
     *dy = oy;
-}
-
-Raw to_raw(const ImgRaw& src) {
-    Raw dst;
-    dst.RGB = src;  // the 8-bit copy of Imgraw.hpp:59-82 (moved in: no second allocation of the image's size)
-    dst.resize(src.width, src.height);
-    return dst;
 }
 
 }  // namespace
@@ -124,8 +124,10 @@ void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::ve
     if (img1.bitCount != 24 || img2.bitCount != 24) throw std::runtime_error("blen2img: both images must be 24-bit RGB");
     if (!RANSAC_feat || RANSAC_num < 2) throw std::runtime_error("blen2img: needs at least two consensus matches");
     sift_amd::StepTimer tm("blen2img");
-    const std::vector<Raw> input = {to_raw(img1), to_raw(img2)};
-    tm.step("8-bit copies");
+    // The reference's 8-bit copies of both images (Blend.cpp:907-916) are made on the device from the float samples
+    // (sift_hip_panorama_pair_f32); focal length and alignment need the sizes only.
+    if (img1.nomal != img2.nomal) throw std::runtime_error("blen2img: both images must hold the same sample range");
+    const Extent input[2] = {{(int)img1.width, (int)img1.height}, {(int)img2.width, (int)img2.height}};
     const float ft = getFocal(HomogMat, img1.size(), img2.size());
     int dx = 0, dy = 0;
     align_offsets(input[0], input[1], RANSAC_feat, RANSAC_num, ft, &dx, &dy);
@@ -145,14 +147,16 @@ void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::ve
     // warping (Blend.cpp:974), multiBandBlend (:994-996) and the canvas loops (:1010-1031; rows and
     // columns that leave the canvas are dropped, where the reference's buffer, tall enough for
     // images of up to 1500 rows only, has no guard) in one device call: two images up, the canvas down
-    std::vector<unsigned char> canvas((size_t)cols * rows2 * 3);
+    std::vector<unsigned char> canvas;
+    sift_amd::reserve_large(canvas, (size_t)cols * rows2 * 3);
+    canvas.resize((size_t)cols * rows2 * 3);
     {
         sift_amd::ContextUse use;
-        check(use.ctx, sift_hip_panorama_pair(use.ctx, input[0].RGB.data(), c0, r0, input[1].RGB.data(), c1, r1, ft, dx, blend_dy,
-                                              top0, left1, top1, canvas.data(), cols, rows2),
-              "sift_hip_panorama_pair");
+        check(use.ctx, sift_hip_panorama_pair_f32(use.ctx, img1.raw_img.data(), c0, r0, img2.raw_img.data(), c1, r1, img1.nomal ? 1 : 0,
+                                                  ft, dx, blend_dy, top0, left1, top1, canvas.data(), cols, rows2),
+              "sift_hip_panorama_pair_f32");
     }
-    tm.step("sift_hip_panorama_pair");
+    tm.step("sift_hip_panorama_pair_f32");
     dst = ImgRaw(canvas, (uint32_t)cols, (uint32_t)rows2, 24);
     tm.step("canvas to float");
 }

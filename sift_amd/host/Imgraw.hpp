@@ -9,6 +9,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "imglib.hpp"
 
 namespace sift_amd {
@@ -36,6 +38,18 @@ inline void parallel_for(size_t n, F fn) {
     fn((size_t)0, std::min(n, per));
     for (auto& x : th) x.join();
 }
+
+// Room for n elements in an empty vector, with the kernel asked to back it by 2 MiB pages where it can: a whole-image
+// vector (tens to hundreds of MB) is fresh memory every time, and taking its page faults 4 KiB at a time costs more
+// than filling it.  A hint only: when the kernel declines, nothing changes.
+template <typename T>
+inline void reserve_large(std::vector<T>& v, size_t n) {
+    v.reserve(n);
+    constexpr uintptr_t huge = (uintptr_t)1 << 21;
+    const uintptr_t lo = ((uintptr_t)v.data() + huge - 1) & ~(huge - 1);
+    const uintptr_t hi = ((uintptr_t)v.data() + v.capacity() * sizeof(T)) & ~(huge - 1);
+    if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+}
 }  // namespace sift_amd
 
 float fastAtan2f(float dy, float dx);  // Imgraw.cpp:29-52, degrees in [0,360]
@@ -48,10 +62,30 @@ private:
 
 public:
     ImgRaw() = default;
+    // Copies of whole images (Sift's and Stitching's constructors take theirs by value, as the reference's do) go into
+    // memory the kernel is asked to back by large pages, in one pass.
+    ImgRaw(const ImgRaw& o) : width(o.width), height(o.height), bitCount(o.bitCount), nomal(o.nomal) {
+        sift_amd::reserve_large(raw_img, o.raw_img.size());
+        raw_img.assign(o.raw_img.begin(), o.raw_img.end());
+    }
+    ImgRaw& operator=(const ImgRaw& o) {
+        if (this != &o) {
+            if (raw_img.capacity() < o.raw_img.size()) {
+                std::vector<types>().swap(raw_img);
+                sift_amd::reserve_large(raw_img, o.raw_img.size());
+            }
+            raw_img.assign(o.raw_img.begin(), o.raw_img.end());
+            width = o.width, height = o.height, bitCount = o.bitCount, nomal = o.nomal;
+        }
+        return *this;
+    }
+    ImgRaw(ImgRaw&&) = default;
+    ImgRaw& operator=(ImgRaw&&) = default;
     ImgRaw(std::vector<types> img, uint32_t width, uint32_t height, uint16_t bits)
         : raw_img(std::move(img)), width(width), height(height), bitCount(bits) {}
     ImgRaw(const std::vector<unsigned char>& img, uint32_t width, uint32_t height, uint16_t bits)
         : width(width), height(height), bitCount(bits) {
+        sift_amd::reserve_large(raw_img, img.size());
         raw_img.resize(img.size());
         // (the 256 possible results of the reference's expression, Imgraw.hpp:30-41, tabulated)
         float lut[256];
@@ -69,7 +103,9 @@ public:
     operator const std::vector<types>&() const { return raw_img; }
     // 8-bit copy (Imgraw.hpp:59-82): what the stitcher's Raw images are filled from
     operator std::vector<unsigned char>() const {
-        std::vector<unsigned char> img(raw_img.size());
+        std::vector<unsigned char> img;
+        sift_amd::reserve_large(img, raw_img.size());
+        img.resize(raw_img.size());
         const float* src = raw_img.data();
         unsigned char* dst = img.data();
         const bool scaled = nomal;
