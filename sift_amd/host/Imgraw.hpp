@@ -18,15 +18,16 @@ namespace sift_amd {
 // never more than the machine reports): the per-pixel format conversions of whole 4K RGB images
 // that the reference's data model asks for (float <-> 8 bit) are memory-bound loops over
 // tens of millions of elements, far longer than the GPU work between them when run on one core.
+// `grain` = the fewest elements worth a thread of their own.
 template <typename F>
-inline void parallel_for(size_t n, F fn) {
+inline void parallel_for(size_t n, F fn, size_t grain = (size_t)1 << 18) {
     static const unsigned want = [] {
         const char* e = std::getenv("SIFT_HOST_THREADS");
         const unsigned t = e ? (unsigned)std::atoi(e) : 8u;
         const unsigned hw = std::thread::hardware_concurrency();
         return std::max(1u, std::min(t, hw ? hw : 1u));
     }();
-    const size_t nt = std::min<size_t>(want, (n + (1u << 18) - 1) >> 18);  // at least 256 k elements per thread
+    const size_t nt = std::min<size_t>(want, (n + grain - 1) / std::max<size_t>(grain, 1));
     if (nt <= 1) {
         fn((size_t)0, n);
         return;

@@ -229,23 +229,28 @@ void Sift::pyramid() {
     }
     // the reference copies its linked list into new Feature[feaNum] (Sift.cpp:207-224)
     Feature* arr = new Feature[n > 0 ? n : 1];
-    for (int i = 0; i < n; i++) {
-        const sift_hip_feat& s = buf[(size_t)i];
-        Feature& f = arr[i];
-        f.size = s.size;
-        f.kai = s.kai;
-        f.sigmaOCT = s.sigmaOCT;
-        f.x = s.x;
-        f.y = s.y;
-        f.mm = s.mm;
-        f.sita = s.sita;
-        for (int k = 0; k < 128; k++) f.descr[k] = (float)s.descr[k];
-        f.d = 128;
-        if (!sub.empty()) {
-            f.img_pt.x = ((float)s.x + sub[(size_t)i * 3 + 0]) / s.size;
-            f.img_pt.y = ((float)s.y + sub[(size_t)i * 3 + 1]) / s.size;
+    const float* subp = sub.empty() ? nullptr : sub.data();
+    const sift_hip_feat* recs = buf;
+    // (each record is 128 byte-to-float conversions: a thread per 2048 features)
+    sift_amd::parallel_for((size_t)n, [=](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            const sift_hip_feat& s = recs[i];
+            Feature& f = arr[i];
+            f.size = s.size;
+            f.kai = s.kai;
+            f.sigmaOCT = s.sigmaOCT;
+            f.x = s.x;
+            f.y = s.y;
+            f.mm = s.mm;
+            f.sita = s.sita;
+            for (int k = 0; k < 128; k++) f.descr[k] = (float)s.descr[k];
+            f.d = 128;
+            if (subp) {
+                f.img_pt.x = ((float)s.x + subp[i * 3 + 0]) / s.size;
+                f.img_pt.y = ((float)s.y + subp[i * 3 + 1]) / s.size;
+            }
         }
-    }
+    }, 2048);
     delete[] FeatStart;
     FeatStart = arr;
     FeatEnd = arr + (n > 0 ? n - 1 : 0);
@@ -274,11 +279,14 @@ Stitching::Stitching(const Sift& desc1, const Sift& desc2)
 size_t Stitching::Match(float matchTh) {
     std::vector<uint8_t> q(feat2_Count * 128), r(feat1_Count * 128);
     auto pack = [](const Feature* f, size_t n, std::vector<uint8_t>& out) {
-        for (size_t i = 0; i < n; i++)
-            for (int k = 0; k < 128; k++) {
-                const float v = f[i].descr[k];  // integer-valued, 0..255 (Sift.cpp:416-420)
-                out[i * 128 + k] = (uint8_t)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
-            }
+        uint8_t* dst = out.data();
+        sift_amd::parallel_for(n, [=](size_t b, size_t e) {
+            for (size_t i = b; i < e; i++)
+                for (int k = 0; k < 128; k++) {
+                    const float v = f[i].descr[k];  // integer-valued, 0..255 (Sift.cpp:416-420)
+                    dst[i * 128 + k] = (uint8_t)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
+                }
+        }, 2048);
     };
     pack(feat2, feat2_Count, q);
     pack(feat1, feat1_Count, r);
