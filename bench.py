@@ -438,6 +438,14 @@ def main():
         t0 = time.perf_counter()
         ctx.panorama_pair(left, right, ft, dxp, bdy, top0, left1, top1, pc, pr)
         extras["panorama_pair_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        # the same from the float images the reference's ImgRaw holds (what the drop-in blen2img calls): four times
+        # the bytes up, no host loop for the 8-bit copies
+        lf, rf = (left / 255.0).astype(np.float32), (right / 255.0).astype(np.float32)
+        ctx.panorama_pair_f32(lf, rf, True, ft, dxp, bdy, top0, left1, top1, pc, pr)
+        t0 = time.perf_counter()
+        ctx.panorama_pair_f32(lf, rf, True, ft, dxp, bdy, top0, left1, top1, pc, pr)
+        extras["panorama_pair_f32_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        del lf, rf
         t0 = time.perf_counter()
         c1, _, _ = ctx.warp_cylinder(left, ft)
         c2, _, _ = ctx.warp_cylinder(right, ft)

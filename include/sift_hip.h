@@ -324,11 +324,13 @@ enum {
  * them; no counterpart in the reference).  key / value: "blur_seg" rows per segment of the
  * streaming column pass (0 = chosen per image); "blur_stream" -1 = where it pays, 0 = never,
  * 1 = wherever an instance exists; "blur_fused" -1 = where it pays, else the longest kernel that
- * takes the one-launch form at any image size; "match_nb" 0 = by query count, 2 or 4;
+ * takes the one-launch form at any image size; "blur_sweep" (float blur only) -1 = the sweeping
+ * one-launch form where it pays, 0 = never, n > 0 = wherever an instance exists, n rows per segment;
+ * "match_nb" 0 = by query count, 2 or 4;
  * "interleave" 0/1; "o3_place" where octave 3 of a single frame runs: 0 = behind octave 2 on the second
  * side stream, 1 = in front of octave 1 on the first, 2 = behind octave 1, 3 = in front of octave 2
  * (default), 4 = on the stream of the octaves beyond it.  The same switches are read from the environment once,
- * in sift_hip_create (SIFT_BLUR_SEG, SIFT_BLUR_STREAM, SIFT_BLUR_FUSED, SIFT_MATCH_NB,
+ * in sift_hip_create (SIFT_BLUR_SEG, SIFT_BLUR_STREAM, SIFT_BLUR_FUSED, SIFT_BLUR_SWEEP, SIFT_MATCH_NB,
  * SIFT_HIP_INTERLEAVE, SIFT_O3_PLACE); no other call looks at the environment. */
 int sift_hip_set_tuning(sift_hip_ctx* ctx, const char* key, int value);
 int sift_hip_profile(sift_hip_ctx* ctx, int enable);

@@ -706,7 +706,7 @@ int sift_hip_create(sift_hip_ctx** out, int device) {
     if (const char* e = std::getenv("SIFT_HIP_SIDE_PRIO")) ctx->side_priority = (e[0] == '0') ? 0 : 1;
     if (const char* e = std::getenv("SIFT_HIP_NSIDE")) ctx->n_side = (e[0] == '1') ? 1 : 2;
     // launch-shape switches: looked up here once, never on a launch path
-    for (const char* key : {"blur_seg", "blur_stream", "blur_fused", "match_nb", "interleave", "o3_place"}) {
+    for (const char* key : {"blur_seg", "blur_stream", "blur_fused", "blur_sweep", "match_nb", "interleave", "o3_place"}) {
         std::string name = key == std::string("interleave") ? "SIFT_HIP_INTERLEAVE"
                          : key == std::string("match_nb")   ? "SIFT_MATCH_NB"
                                                             : std::string("SIFT_") + key;
@@ -825,6 +825,7 @@ int sift_hip_set_tuning(sift_hip_ctx* ctx, const char* key, int value) {
     if (k == "blur_seg") t.blur_seg = std::max(0, value);
     else if (k == "blur_stream") t.blur_stream = value < 0 ? -1 : (value != 0);
     else if (k == "blur_fused") t.blur_fused = value < 0 ? -1 : value;
+    else if (k == "blur_sweep") t.blur_sweep = value < 0 ? -1 : value;
     else if (k == "match_nb") { if (value != 0 && value != 2 && value != 4) return SIFT_HIP_ERR_ARG; t.match_nb = value; }
     else if (k == "interleave") t.interleave = value != 0;
     else if (k == "o3_place") { if (value < 0 || value > 4) return SIFT_HIP_ERR_ARG; t.o3_place = value; }

@@ -70,13 +70,14 @@ struct OctavePlan {        // host-side constants of one octave (Sift.cpp:145-18
 };
 
 // Launch-shape switches for A/B measurements and tests.  They are read from the environment
-// once, when the context is created (SIFT_BLUR_SEG, SIFT_BLUR_STREAM, SIFT_BLUR_FUSED,
+// once, when the context is created (SIFT_BLUR_SEG, SIFT_BLUR_STREAM, SIFT_BLUR_FUSED, SIFT_BLUR_SWEEP,
 // SIFT_MATCH_NB, SIFT_HIP_INTERLEAVE, SIFT_O3_PLACE), and changed on a live context only through
 // sift_hip_set_tuning: no launch path looks at the environment.
 struct Tuning {
     int blur_seg = 0;      // streaming column pass: rows per segment (0 = chosen per image)
     int blur_stream = -1;  // streaming column pass: -1 = where it pays, 0 = never, 1 = wherever an instance exists
     int blur_fused = -1;   // one-launch blur: -1 = where it pays, else the longest kernel that takes it at any image size
+    int blur_sweep = -1;   // sweeping one-launch blur (float arithmetic): -1 = where it pays, 0 = never, n > 0 = wherever an instance exists, n rows per segment
     int match_nb = 0;      // matcher: 32-query blocks per wave, 0 = by query count, else 2 or 4
     int interleave = 1;    // single frames: pyramids of the streams' first octaves enqueued level by level in turn
     int o3_place = 3;      // single frames of four octaves and more: where octave 3 runs (see enqueue_extract)

@@ -851,6 +851,22 @@ __device__ __forceinline__ void conv_run(const float* __restrict__ src, int stri
     }
 }
 
+// conv_run for float accumulators with the taps in registers, the symmetric half only (g[m] = tap m = tap K-1-m)
+template <int K, int P>
+__device__ __forceinline__ void conv_run_sym(const float* __restrict__ src, const float (&g)[K / 2 + 1], float (&acc)[P]) {
+    Window<float, P> win;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        acc[p] = 0;
+        win.set(p, src[p]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        win.step(acc, k % P, g[k <= K / 2 ? k : K - 1 - k]);
+        if (k + P < K + P - 1) win.set(k % P, src[k + P]);
+    }
+}
+
 template <int K>
 struct FusedGeom {
     static constexpr int T = 64;                          // tile edge
@@ -980,9 +996,231 @@ static bool blur_fused(sift_hip_ctx* ctx, hipStream_t st, const float* src, floa
     }
 }
 
+// ---- both passes in one launch, sweeping down the image (float arithmetic) ------------
+// The one-launch form above pays (64+K-1)^2 / 64^2 times the loads and (64+K-1)/64 times the row-pass
+// arithmetic of a level, which at 39 taps is 2.5x and 1.6x.  Here a 256-thread workgroup owns a strip of
+// TW = 256*NU output columns and a segment of `seg` output rows and walks down it RS = 8 input rows at a
+// time: the 8 rows (plus K-1 columns of halo) go global -> LDS directly, two buffers in turn so that the
+// next step's rows are in flight while this step computes; the row pass (the same sliding window over 8
+// consecutive outputs as everywhere else; a unit = one of the 8 rows x one block of 8 columns, pitch 1 mod 8
+// so that the 8 x 8 units of a wave hit 64 banks) writes the 8 row-blurred rows to a third LDS array; for
+// the column pass a thread owns NU columns and keeps the last KR >= K row-blurred values of each in
+// REGISTERS (a ring whose slot is the row's number mod KR: the loop body covers KR rows, so every slot
+// index is a compile-time constant), pushes the 8 new values one by one and, once K rows are in, forms
+// an output row from the ring after every push.  Loads: (TW+K-1)/TW x (seg+K-1)/seg of the level; row-pass
+// arithmetic: (seg+K-1)/seg; the column pass costs exactly its own multiply-adds and reads nothing but its
+// 8 new values per step.  Every output receives the same fused multiply-adds in the same (ascending tap)
+// order as in the other float kernels, so the results are identical to theirs.
+template <int K, int NU>
+struct SweepGeom {
+    static constexpr int RS = 8;                           // input rows per step
+    static constexpr int KR = (K + RS - 1 + RS - 1) / RS * RS;  // ring length: K values of the oldest pending output + the RS-1 newer rows
+    static constexpr int TW = 256 * NU;                    // output columns of a strip
+    static constexpr int NINW = TW + K - 1;                // input columns of a strip
+    static constexpr int PIN = ((NINW + 6) / 8) * 8 + 1;   // pitch of the input rows
+    static constexpr int POUT = TW + 1;                    // pitch of the row-blurred rows
+    static constexpr int NCH = (NINW + 63) / 64;           // 64-column chunks of an input row
+    static constexpr size_t lds_bytes = (size_t)(2 * RS * PIN + RS * POUT) * sizeof(float);
+};
+
+#ifdef SWEEP_TRACE
+__device__ unsigned long long g_sweep_trace[6 * 8192];  // per workgroup: start, end (shader clock), hardware id, xcc id, start, end (100 MHz clock)
+#endif
+
+template <int K, int NU>
+__global__ __launch_bounds__(256) void blur_sweep_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
+                                                         int H, const float* __restrict__ taps, int seg) {
+    using G = SweepGeom<K, NU>;
+    constexpr int R = K >> 1, RS = G::RS, KR = G::KR, PIN = G::PIN, POUT = G::POUT, NCH = G::NCH, NINW = G::NINW;
+    extern __shared__ float s[];
+    float* s_rb = s + 2 * RS * PIN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SWEEP_TRACE
+    const unsigned long long t_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int x0 = blockIdx.x * G::TW;
+    const int y0 = blockIdx.y * seg, y1 = min(y0 + seg, H);
+    const int npush = (y1 - y0) + K - 1;  // input rows y0-R .. y1-1+R, clamped to the image as the column pass clamps them
+    const int nsteps = (npush + RS - 1) / RS;
+    int col[NCH];  // this lane's column in each chunk, clamped as the row pass clamps it
+#pragma unroll
+    for (int ci = 0; ci < NCH; ci++) col[ci] = min(max(x0 - R + 64 * ci + lane, 0), W - 1);
+    auto load_step = [&](int st) __attribute__((always_inline)) {
+        float* buf = s + (st & 1) * (RS * PIN);
+#pragma unroll
+        for (int jj = 0; jj < RS / 4; jj++) {
+            const int j = wave + 4 * jj;
+            const float* row = in + (size_t)min(max(y0 - R + st * RS + j, 0), H - 1) * W;
+#pragma unroll
+            for (int ci = 0; ci < NCH; ci++)
+                if (64 * ci + lane < NINW)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + col[ci]),
+                                                     (__attribute__((address_space(3))) void*)(buf + j * PIN + 64 * ci), 4, 0, 0);
+        }
+    };
+    // the taps are symmetric bit for bit (built from the centre outwards): R+1 scalars serve all K
+    float g[R + 1];
+#pragma unroll
+    for (int m = 0; m <= R; m++) g[m] = taps[m];
+    // the ring in both pairings, (2m, 2m+1) and (2m+1, 2m+2), so that the output rows j and j+1, whose tap k reads
+    // the consecutive slots i and i+1, share one packed multiply-add whatever the parity of i (cf. Window)
+    float_pair re[NU][KR / 2], ro[NU][KR / 2];
+#pragma unroll
+    for (int n = 0; n < NU; n++)
+#pragma unroll
+        for (int i = 0; i < KR / 2; i++) re[n][i] = ro[n][i] = float_pair{0.f, 0.f};
+    // Output rows wait in registers for one step: a wave must see its loads of the next rows complete (vmcnt(0), the
+    // counter does not tell loads from stores) at the top of every step, and stores issued just before that wait
+    // would put their whole round trip to memory into it.  Issued right behind the wait, they have a step to finish.
+    float_pair pend[NU][RS / 2];
+    int pend_st = -1;  // step whose outputs are pending (uniform)
+    auto flush = [&]() __attribute__((always_inline)) {
+        if (pend_st < 0) return;
+#pragma unroll
+        for (int n = 0; n < NU; n++) {
+            if (x0 + tid + 256 * n < W) {
+#pragma unroll
+                for (int j = 0; j < RS; j++) {
+                    const int sidx = pend_st * RS + j;
+                    const int yo = y0 + sidx - (K - 1);
+                    if (sidx >= K - 1 && yo < y1)
+                        out[(size_t)yo * W + x0 + tid + 256 * n] = (j & 1) ? pend[n][j >> 1].y : pend[n][j >> 1].x;
+                }
+            }
+        }
+        pend_st = -1;
+    };
+    load_step(0);
+    for (int st0 = 0; st0 < nsteps; st0 += KR / RS) {
+#pragma unroll
+        for (int q = 0; q < KR / RS; q++) {
+            const int st = st0 + q;
+            if (st >= nsteps) break;  // uniform
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's rows of step st have landed
+            __syncthreads();                      // ... and everybody's; the column pass of step st-1 is done with s_rb
+            flush();
+            if (st + 1 < nsteps) load_step(st + 1);
+            const float* buf = s + (st & 1) * (RS * PIN);
+#pragma unroll
+            for (int n = 0; n < NU; n++) {
+                const int j = lane & 7, xb = (lane >> 3) + 8 * wave + 32 * n;
+                float acc[8];
+                conv_run_sym<K, 8>(buf + j * PIN + xb * 8, g, acc);
+                float* d = s_rb + j * POUT + xb * 8;
+#pragma unroll
+                for (int p = 0; p < 8; p++) d[p] = acc[p];
+            }
+            __syncthreads();
+            // the 8 new rows enter the ring (slot = q*RS + j, a compile-time constant after unrolling) ...
+#pragma unroll
+            for (int j = 0; j < RS; j++)
+#pragma unroll
+                for (int n = 0; n < NU; n++) {
+                    const float v = s_rb[j * POUT + tid + 256 * n];
+                    const int slot = q * RS + j;
+                    if (slot & 1) {
+                        re[n][slot >> 1].y = v;
+                        ro[n][slot >> 1].x = v;
+                    } else {
+                        re[n][slot >> 1].x = v;
+                        ro[n][((slot + KR - 2) % KR) >> 1].y = v;
+                    }
+                }
+            // ... and the 8 output rows they complete are formed side by side: independent chains, two rows per
+            // packed multiply-add, each adding its products in ascending tap order
+            if (st * RS + RS - 1 >= K - 1) {  // uniform: at least the last of them has all its K rows
+#pragma unroll
+                for (int n = 0; n < NU; n++) {
+#pragma unroll
+                    for (int j = 0; j < RS / 2; j++) pend[n][j] = float_pair{0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        const float gk = g[k <= R ? k : K - 1 - k];
+                        const float_pair gg = {gk, gk};
+#pragma unroll
+                        for (int j = 0; j < RS / 2; j++) {
+                            const int i = (q * RS + 2 * j - (K - 1) + k + 2 * KR) % KR;  // slot of row 2j's tap k; row 2j+1 reads i+1
+                            const float_pair v = (i & 1) ? ro[n][i >> 1] : re[n][i >> 1];
+                            pend[n][j] = __builtin_elementwise_fma(v, gg, pend[n][j]);
+                        }
+                    }
+                }
+                pend_st = st;
+            }
+        }
+    }
+    flush();
+#ifdef SWEEP_TRACE
+    if (tid == 0) {
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wg < 8192) {
+            g_sweep_trace[6 * wg + 0] = t_begin;
+            g_sweep_trace[6 * wg + 1] = __builtin_readcyclecounter();
+            g_sweep_trace[6 * wg + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+            g_sweep_trace[6 * wg + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+            g_sweep_trace[6 * wg + 4] = r_begin;
+            g_sweep_trace[6 * wg + 5] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
+}
+
+// Rows per segment of the sweeping form: about `per_cu` workgroups per compute unit, in whole steps.
+template <int K, int NU>
+static bool launch_sweep(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* dst, int W, int H,
+                         const float* d_taps, int seg_rows) {
+    using G = SweepGeom<K, NU>;
+    static_assert(G::lds_bytes <= (size_t)kMaxColLds, "strip buffers must fit the default LDS limit");
+    const int strips = (W + G::TW - 1) / G::TW;
+    int seg = seg_rows;
+    if (seg <= 0) {
+        const int segs = std::max(1, 256 * 3 / strips);
+        seg = (H + segs - 1) / segs;
+    }
+    seg = std::max(G::RS, (seg + G::RS - 1) / G::RS * G::RS);
+    const int nseg = (H + seg - 1) / seg;
+    if (nseg > 65535) return false;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(blur_sweep_kernel<K, NU>), dim3(strips, nseg), dim3(256), G::lds_bytes, st, src,
+                       dst, W, H, d_taps, seg);
+    return true;
+}
+
+// Whether the sweeping one-launch form takes this level (float arithmetic only); *seg = rows per segment (0: chosen
+// at the launch).
+static bool sweep_wanted(const sift_hip_ctx* ctx, int W, int H, int K, int* seg) {
+    const int mode = ctx->tune.blur_sweep;  // -1: where it pays, 0: never, n > 0: always, n rows per segment
+    if (mode == 0 || !(K == 21 || K == 29 || K == 39)) return false;
+    *seg = 0;
+    if (mode > 0) {
+        *seg = mode;
+        return true;
+    }
+    // the segments must be long against the K-1 rows a segment consumes before its first output
+    const int strips = (W + 255) / 256;
+    const int segs = std::max(1, 256 * 3 / strips);
+    return (H + segs - 1) / segs >= 3 * K;
+}
+
+static bool blur_sweep(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* dst, int W, int H,
+                       const float* d_taps, int K, int seg) {
+    switch (K) {
+        case 21: return launch_sweep<21, 1>(ctx, st, src, dst, W, H, d_taps, seg);
+        case 29: return launch_sweep<29, 1>(ctx, st, src, dst, W, H, d_taps, seg);
+        case 39: return launch_sweep<39, 1>(ctx, st, src, dst, W, H, d_taps, seg);
+        default: return false;
+    }
+}
+
 template <typename ACC, int P>
 static void launch_blur_tp(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* tmp, float* dst, int W, int H,
                            const float* d_taps, int K) {
+    if constexpr (sizeof(ACC) == sizeof(float)) {
+        int seg = 0;
+        if (src != dst && sweep_wanted(ctx, W, H, K, &seg)) {
+            ProfScope ps(ctx, SIFT_HIP_K_BLUR_FUSED, st);
+            if (blur_sweep(ctx, st, src, dst, W, H, d_taps, K, seg)) return;
+        }
+    }
     if (src != dst && fused_wanted<ACC>(ctx, W, H, K)) {
         ProfScope ps(ctx, SIFT_HIP_K_BLUR_FUSED, st);
         if (blur_fused<ACC>(ctx, st, src, dst, W, H, d_taps, K)) return;

@@ -534,6 +534,51 @@ def test_one_launch_blur_bit_exact_on_ragged_shapes(sift, oracle):
         sift.set_tuning("blur_fused", -1)
 
 
+def test_sweeping_one_launch_blur_equals_the_other_float_kernels(sift):
+    """The sweeping one-launch form of the float blur (a workgroup walks down a strip of 256 columns, 8 input
+    rows per step, the column pass from a register ring; by itself only used where the segments are long
+    against the kernel) forced onto small and ragged images with segment lengths that cut the strips at
+    awkward rows: every tap count it is instantiated for, widths that are not multiples of the strip, images
+    smaller than the kernel, one-row and one-column images, negative inputs and exact zeros.  Its results must
+    equal the two-launch float kernels bit for bit (same multiply-adds in the same order), which
+    tests/test_gpu_fast_blur.py grades against the exact mode."""
+    rng = np.random.default_rng(43)
+    shapes = [(200, 131), (256, 64), (1, 77), (130, 1), (65, 40), (333, 95), (513, 130), (257, 9)]
+    for p, K in ((3.2, 21), (4.5254836, 29), (6.4, 39)):
+        assert len(sift_amd.gau_matrix(p)) == K
+        for i, (w, h) in enumerate(shapes):
+            img = (rng.random((h, w), dtype=np.float32) - (0.5 if i == 3 else 0.0)).astype(np.float32)
+            if i % 2:
+                img[rng.random((h, w)) < 0.3] = 0.0
+            sift.set_tuning("blur_sweep", 0)
+            sift.set_tuning("blur_fused", 0)
+            want = bits(sift.gau_blur(img, p, blur_mode=1))
+            for seg in (1, 8, 24, 56, 1000):
+                sift.set_tuning("blur_sweep", seg)
+                assert np.array_equal(bits(sift.gau_blur(img, p, blur_mode=1)), want), (K, w, h, seg)
+    sift.set_tuning("blur_sweep", -1)
+    sift.set_tuning("blur_fused", -1)
+    # the launch count shows the form in use: an 8192 x 3072 image takes it for its 21-tap level, and the exact
+    # mode never does
+    img = rng.random((3072, 8192), dtype=np.float32)
+    sift.profile(True)
+    sift.profile_read(reset=True)
+    out = sift.gau_blur(img, 3.2, blur_mode=1)
+    prof = sift.profile_read(reset=True)
+    assert prof["blur_fused"][1] == 1 and prof["blur_row"][1] == 0 and prof["blur_col"][1] == 0
+    sift.set_tuning("blur_sweep", 0)
+    try:
+        assert np.array_equal(bits(out), bits(sift.gau_blur(img, 3.2, blur_mode=1)))
+        sift.set_tuning("blur_sweep", 64)
+        sift.profile_read(reset=True)
+        sift.gau_blur(img, 3.2)
+        prof = sift.profile_read(reset=True)
+        assert prof["blur_fused"][1] == 0 and prof["blur_row"][1] == 1
+    finally:
+        sift.profile(False)
+        sift.set_tuning("blur_sweep", -1)
+
+
 def test_kernel_longer_than_the_image_bit_exact(sift, oracle):
     """Images shorter or narrower than the kernel go through the passes that stage the whole row /
     column strip once and clamp on the LDS read: every outputs-per-thread variant (chosen by pixel
