@@ -100,6 +100,28 @@ void launch_first(sift_hip_ctx* ctx, hipStream_t st, const float* src, int w, in
 constexpr int kMaxColLds = 64 * 1024;   // largest LDS tile a blur pass requests without asking for more
 constexpr int kBigColLds = 150 * 1024;  // gfx950 lets a workgroup address 160 KB once the kernel opts in
 
+// Workgroup trace for tools/microbench_sweep.hip (compiled in only with -DWG_TRACE): per workgroup its start and
+// end on the shader clock and on the 100 MHz clock all compute units share, and where it ran.
+#ifdef WG_TRACE
+__device__ unsigned long long g_wg_trace[6 * 32768];
+#define TRACE_BEGIN() const unsigned long long t_begin__ = __builtin_readcyclecounter(), r_begin__ = __builtin_amdgcn_s_memrealtime()
+#define TRACE_END(wg__)                                                                                          \
+    do {                                                                                                         \
+        if (threadIdx.x == 0 && (unsigned)(wg__) < 32768u) {                                                     \
+            unsigned long long* t__ = sifthip::g_wg_trace + 6 * (size_t)(wg__);                                  \
+            t__[0] = t_begin__;                                                                                  \
+            t__[1] = __builtin_readcyclecounter();                                                               \
+            t__[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  /* HW_ID */                   \
+            t__[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); /* XCC_ID */                  \
+            t__[4] = r_begin__;                                                                                  \
+            t__[5] = __builtin_amdgcn_s_memrealtime();                                                           \
+        }                                                                                                        \
+    } while (0)
+#else
+#define TRACE_BEGIN() ((void)0)
+#define TRACE_END(wg__) ((void)0)
+#endif
+
 // ---- separable blur ----------------------------------------------------------------
 // P = outputs per thread along the filter direction: 8 for large octaves (one LDS
 // read per 8 MACs), 4 and 2 for smaller ones, which otherwise cannot fill 1024 SIMDs.
@@ -209,7 +231,7 @@ __device__ __forceinline__ void conv_blocked(RD rd, const float* __restrict__ ta
 // LDS index with one pad word per P so that lanes P floats apart hit distinct banks
 // (lane stride P+1 words, odd).
 template <int P>
-__device__ __forceinline__ int padx(int i) { return i + i / P; }
+__host__ __device__ __forceinline__ int padx(int i) { return i + i / P; }
 
 // Row pass: one wave per 512-pixel run of one row.  LDS holds the run plus halo.
 template <typename ACC, int P>
@@ -217,6 +239,7 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
                                                       int H, const float* __restrict__ taps, int K) {
     extern __shared__ float s[];
     const int lane = threadIdx.x;
+    TRACE_BEGIN();
     const int r = K >> 1;
     const int y = blockIdx.y;
     const int x0 = blockIdx.x * (64 * P);
@@ -287,6 +310,7 @@ __global__ __launch_bounds__(64) void blur_row_kernel(const float* __restrict__ 
         for (int p = 0; p < P; p++)
             if (x0 + base + p < W) o[p] = (float)acc[p];
     }
+    TRACE_END(blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Row pass for kernels too long for an LDS run (deep octaves of very large images:
@@ -1023,10 +1047,6 @@ struct SweepGeom {
     static constexpr size_t lds_bytes = (size_t)(2 * RS * PIN + RS * POUT) * sizeof(float);
 };
 
-#ifdef SWEEP_TRACE
-__device__ unsigned long long g_sweep_trace[6 * 8192];  // per workgroup: start, end (shader clock), hardware id, xcc id, start, end (100 MHz clock)
-#endif
-
 template <int K, int NU>
 __global__ __launch_bounds__(256) void blur_sweep_kernel(const float* __restrict__ in, float* __restrict__ out, int W,
                                                          int H, const float* __restrict__ taps, int seg) {
@@ -1035,9 +1055,7 @@ __global__ __launch_bounds__(256) void blur_sweep_kernel(const float* __restrict
     extern __shared__ float s[];
     float* s_rb = s + 2 * RS * PIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef SWEEP_TRACE
-    const unsigned long long t_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
-#endif
+    TRACE_BEGIN();
     const int x0 = blockIdx.x * G::TW;
     const int y0 = blockIdx.y * seg, y1 = min(y0 + seg, H);
     const int npush = (y1 - y0) + K - 1;  // input rows y0-R .. y1-1+R, clamped to the image as the column pass clamps them
@@ -1150,19 +1168,7 @@ __global__ __launch_bounds__(256) void blur_sweep_kernel(const float* __restrict
         }
     }
     flush();
-#ifdef SWEEP_TRACE
-    if (tid == 0) {
-        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
-        if (wg < 8192) {
-            g_sweep_trace[6 * wg + 0] = t_begin;
-            g_sweep_trace[6 * wg + 1] = __builtin_readcyclecounter();
-            g_sweep_trace[6 * wg + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-            g_sweep_trace[6 * wg + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
-            g_sweep_trace[6 * wg + 4] = r_begin;
-            g_sweep_trace[6 * wg + 5] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-#endif
+    TRACE_END(blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Rows per segment of the sweeping form: about `per_cu` workgroups per compute unit, in whole steps.
@@ -1195,10 +1201,15 @@ static bool sweep_wanted(const sift_hip_ctx* ctx, int W, int H, int K, int* seg)
         *seg = mode;
         return true;
     }
-    // the segments must be long against the K-1 rows a segment consumes before its first output
+    // About three workgroups per compute unit, but no segment shorter than 64 rows; the segments must be long
+    // against the K-1 rows a segment consumes before its first output.  (Measured on 3840 x 2160: 39 taps 34.9 us
+    // in segments of 64 rows against 40.0 for the tiled one-launch form, 21 and 29 taps even with it.)
     const int strips = (W + 255) / 256;
     const int segs = std::max(1, 256 * 3 / strips);
-    return (H + segs - 1) / segs >= 3 * K;
+    const int rows = std::max(64, (H + segs - 1) / segs);
+    *seg = rows;
+    if ((size_t)W * H < ((size_t)3 << 20) || H < rows) return false;
+    return rows >= 3 * K || K == 39;
 }
 
 static bool blur_sweep(sift_hip_ctx* ctx, hipStream_t st, const float* src, float* dst, int W, int H,
