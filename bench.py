@@ -257,7 +257,7 @@ def main():
             fj = json.load(open(ffiles[-1]))
             if fj.get("kernel_source_sha256") == src_hash:
                 wantf = {"blur_col": ("blur_col_kernel<float, 8>",), "blur_row": ("blur_row_kernel<float, 8>",),
-                         "blur_fused": ("blur_fused_kernel<float",)}[domf]
+                         "blur_fused": ("blur_fused_kernel<float", "blur_sweep_kernel")}[domf]
                 kk = [v for k, v in fj["kernels"].items() if k.startswith(wantf)]
                 nl = sum(v["launches_per_frame"] for v in kk)
                 if kk and nl:
@@ -268,7 +268,7 @@ def main():
             else:
                 traffic_f_note = "profiles/%s was measured on other kernel sources: not reported" % os.path.basename(ffiles[-1])
         roofline_fast = {
-            "blur_mode": 1, "bound": "hbm", "kernel": domf + " class (dominant by total time)",
+            "blur_mode": 1, "bound": "hbm", "kernel": domf + " class (dominant by total time" + ("; blur_fused_kernel<float, K> and blur_sweep_kernel<K, 1>)" if domf == "blur_fused" else ")"),
             "achieved": round(alg_l / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(alg_l / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_f,
             "traffic_source": traffic_f_note,
