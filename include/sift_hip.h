@@ -181,6 +181,24 @@ int sift_hip_match_u8_dev(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const u
 int sift_hip_match_u8_noalloc(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_r, int nr, float ratio,
                               int ratio_form, int32_t* d_best, int32_t* d_d1, int32_t* d_d2);
 
+/* ---- descriptors that stay on the device between the extract and the match: the call site of the
+ * matcher (Stitching::Check, Sift/Sift.cpp:669-676) matches two feature arrays that two extracts
+ * produced a moment earlier; their descriptor bytes are still in device memory then.
+ * sift_hip_keep_descriptors copies the descriptors of the features that the LAST extract call on this
+ * context returned (any extract entry point; after a batch call: its last frame) into a device buffer
+ * of their own, n x 128 bytes in output order, owned by the returned set; *n (optional) receives the
+ * count.  SIFT_HIP_ERR_ARG if no extract has delivered features since the last one began.
+ * sift_hip_match_kept is sift_hip_match_u8 on two such sets (both made on this context's device):
+ * nothing is packed or uploaded; best / d1 / d2 are host arrays of the query set's count.  Results equal
+ * sift_hip_match_u8 on the descr bytes of the two feature arrays.  A set is freed with
+ * sift_hip_release_descriptors (before its context is destroyed, or with ctx = NULL afterwards). */
+typedef struct sift_hip_descr_set sift_hip_descr_set;
+int sift_hip_keep_descriptors(sift_hip_ctx* ctx, sift_hip_descr_set** set, int* n);
+void sift_hip_release_descriptors(sift_hip_ctx* ctx, sift_hip_descr_set* set);
+int sift_hip_descriptor_count(const sift_hip_descr_set* set);
+int sift_hip_match_kept(sift_hip_ctx* ctx, const sift_hip_descr_set* q, const sift_hip_descr_set* r, float ratio,
+                        int ratio_form, int32_t* best, int32_t* d1, int32_t* d2);
+
 /* Multi-GPU form, one process per GPU: every rank passes its own shard of the references
  * (the same nr_local on every rank) and its own queries; the shards are all-gathered with
  * ncclAllGather on the caller's communicator (comm: an ncclComm_t of nranks ranks; RCCL over

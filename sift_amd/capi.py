@@ -134,6 +134,10 @@ def load_library() -> C.CDLL:
                                              C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
         "sift_hip_panorama_pair_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
+        "sift_hip_keep_descriptors": (C.c_int, [vp, C.POINTER(vp), ip]),
+        "sift_hip_release_descriptors": (None, [vp, vp]),
+        "sift_hip_descriptor_count": (C.c_int, [vp]),
+        "sift_hip_match_kept": (C.c_int, [vp, vp, vp, C.c_float, C.c_int, vp, vp, vp]),
         "sift_hip_set_tuning": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "sift_hip_profile": (C.c_int, [vp, C.c_int]),
         "sift_hip_profile_read": (C.c_int, [vp, fp, ip, C.c_int]),
@@ -342,6 +346,26 @@ class SiftHip:
         """sift_hip_match_u8_noalloc: device pointers, no allocation inside the call, sizes bounded."""
         self._check(self.lib.sift_hip_match_u8_noalloc(self.h, _ptr(d_q), nq, _ptr(d_r), nr, ratio, ratio_form,
                                                        _ptr(d_best), _ptr(d_d1), _ptr(d_d2)))
+
+    def keep_descriptors(self):
+        """sift_hip_keep_descriptors: the descriptors of the last extract's features stay on the device; returns
+        (opaque set, count).  Free the set with release_descriptors."""
+        h = C.c_void_p()
+        n = C.c_int(0)
+        self._check(self.lib.sift_hip_keep_descriptors(self.h, C.byref(h), C.byref(n)))
+        return h, n.value
+
+    def release_descriptors(self, dset):
+        self.lib.sift_hip_release_descriptors(self.h, dset)
+
+    def match_kept(self, qset, rset, ratio: float = 0.4, ratio_form: int = 0):
+        """sift_hip_match_kept: match_u8 on two kept descriptor sets, nothing packed or uploaded."""
+        nq = self.lib.sift_hip_descriptor_count(qset)
+        best = np.full(max(nq, 0), -1, np.int32)
+        d1 = np.zeros(max(nq, 0), np.int32)
+        d2 = np.zeros(max(nq, 0), np.int32)
+        self._check(self.lib.sift_hip_match_kept(self.h, qset, rset, ratio, ratio_form, _ptr(best), _ptr(d1), _ptr(d2)))
+        return best, d1, d2
 
     # ---- RANSAC homography over the matches ------------------------------------------
     def ransac_homog(self, q_feats: np.ndarray, r_feats: np.ndarray, best: np.ndarray, m: int = 4,

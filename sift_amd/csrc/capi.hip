@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 #include <dlfcn.h>
 
@@ -301,6 +302,8 @@ static int check_async(sift_hip_ctx* ctx, const char* what) {
 // then waits for that work before it feeds the side streams.
 static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h, const sift_hip_params& prm,
                            int feat_cap, int cand_cap, bool want_hist, int frame_state) {
+    ctx->last_feat_ptr.clear();  // the octaves' record arrays are about to be rewritten
+    ctx->last_feat_cnt.clear();
     int rc = build_plan(ctx, w, h, prm);
     if (rc) return rc;
     const Plan& pl = ctx->plan;
@@ -526,9 +529,13 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
     }
     long long total = 0;
     int copied = 0;
+    ctx->last_feat_ptr.assign((size_t)noct, nullptr);
+    ctx->last_feat_cnt.assign((size_t)noct, 0);
     for (int oi = 0; oi < noct; oi++) {
         const int cnt = ctx->h_counters[G_OCT_FEATS + oi];
         const int m = std::max(0, std::min(cnt, cap - copied));  // the octave's buffer holds at most cap
+        ctx->last_feat_ptr[(size_t)oi] = (const sift_hip_feat*)ctx->lanes[oi].feat.p;
+        ctx->last_feat_cnt[(size_t)oi] = m;
         if (m > 0) {
             if (!(oi == 0 && early == m) &&
                 !hip_ok(ctx, hipMemcpyAsync(out + copied, ctx->lanes[oi].feat.p, (size_t)m * sizeof(sift_hip_feat),
@@ -1430,6 +1437,83 @@ int sift_hip_last_offsets(sift_hip_ctx* ctx, float* xyz, int cap) {
     const int n = (int)std::min<size_t>(ctx->h_sub.size() / 3, (size_t)cap);
     if (n > 0) std::memcpy(xyz, ctx->h_sub.data(), (size_t)n * 3 * sizeof(float));
     return n;
+}
+
+struct sift_hip_descr_set {
+    uint8_t* d = nullptr;  // n x 128 bytes
+    int n = 0;
+    int device = 0;
+};
+
+int sift_hip_keep_descriptors(sift_hip_ctx* ctx, sift_hip_descr_set** set, int* n) {
+    if (bad_ctx(ctx) || !set) return SIFT_HIP_ERR_ARG;
+    *set = nullptr;
+    if (ctx->last_feat_ptr.empty()) {
+        ctx->last_error = "keep_descriptors: no extract of this context has delivered features since the last one began";
+        return SIFT_HIP_ERR_ARG;
+    }
+    long long total = 0;
+    for (int c : ctx->last_feat_cnt) total += c;
+    sift_hip_descr_set* ds = new (std::nothrow) sift_hip_descr_set;
+    if (!ds) return SIFT_HIP_ERR_HIP;
+    ds->n = (int)total;
+    ds->device = ctx->device;
+    if (!hip_ok(ctx, hipMalloc((void**)&ds->d, (size_t)std::max<long long>(total, 1) * 128), "keep_descriptors")) {
+        delete ds;
+        return SIFT_HIP_ERR_HIP;
+    }
+    size_t done = 0;
+    for (size_t oi = 0; oi < ctx->last_feat_ptr.size(); oi++) {
+        launch_gather_descr(ctx, ctx->stream, ctx->last_feat_ptr[oi], ctx->last_feat_cnt[oi], ds->d + done * 128);
+        done += (size_t)ctx->last_feat_cnt[oi];
+    }
+    // the record arrays may be rewritten by the next extract as soon as this call returns
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "keep_descriptors")) {
+        hipFree(ds->d);
+        delete ds;
+        return SIFT_HIP_ERR_HIP;
+    }
+    const int rc = check_async(ctx, "keep_descriptors");
+    if (rc) {
+        hipFree(ds->d);
+        delete ds;
+        return rc;
+    }
+    *set = ds;
+    if (n) *n = ds->n;
+    return SIFT_HIP_OK;
+}
+
+void sift_hip_release_descriptors(sift_hip_ctx* ctx, sift_hip_descr_set* set) {
+    if (!set) return;
+    if (ctx && ctx->device == set->device) hipSetDevice(ctx->device);
+    if (set->d) hipFree(set->d);
+    delete set;
+}
+
+int sift_hip_descriptor_count(const sift_hip_descr_set* set) { return set ? set->n : SIFT_HIP_ERR_ARG; }
+
+int sift_hip_match_kept(sift_hip_ctx* ctx, const sift_hip_descr_set* q, const sift_hip_descr_set* r, float ratio,
+                        int ratio_form, int32_t* best, int32_t* d1, int32_t* d2) {
+    if (bad_ctx(ctx) || !q || !r || (q->n > 0 && !best)) return SIFT_HIP_ERR_ARG;
+    if (q->device != ctx->device || r->device != ctx->device) return SIFT_HIP_ERR_ARG;
+    if (ratio_form != 0 && ratio_form != 1) return SIFT_HIP_ERR_ARG;
+    const int nq = q->n, nr = r->n;
+    if (nq == 0) return SIFT_HIP_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->best, (size_t)nq * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d1, (size_t)nq * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d2, (size_t)nq * 4))) return rc;
+    rc = run_match(ctx, q->d, nq, r->d, nr, ratio, ratio_form, (int32_t*)ctx->best.p, (int32_t*)ctx->d1.p, (int32_t*)ctx->d2.p);
+    if (rc) return rc;
+    if (!hip_ok(ctx, hipMemcpyAsync(best, ctx->best.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream), "read matches"))
+        return SIFT_HIP_ERR_HIP;
+    if (d1 && !hip_ok(ctx, hipMemcpyAsync(d1, ctx->d1.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream), "read matches"))
+        return SIFT_HIP_ERR_HIP;
+    if (d2 && !hip_ok(ctx, hipMemcpyAsync(d2, ctx->d2.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream), "read matches"))
+        return SIFT_HIP_ERR_HIP;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "match")) return SIFT_HIP_ERR_HIP;
+    return check_async(ctx, "match");
 }
 
 int sift_hip_profile(sift_hip_ctx* ctx, int enable) {

@@ -130,6 +130,10 @@ struct sift_hip_ctx {
     hipEvent_t ev_side2[2] = {nullptr, nullptr};  // ... on `side_stream2`
     hipEvent_t ev_side3[2] = {nullptr, nullptr};  // ... and on `side_stream3`
     std::vector<float> h_sub;  // offsets of the last extract with subpixel = 1 (3 per feature)
+    // where the records of the last extract that delivered features still sit in device memory: per octave the
+    // array and the number of records that went to the caller (sift_hip_keep_descriptors); empty = nothing to keep
+    std::vector<const sift_hip_feat*> last_feat_ptr;
+    std::vector<int> last_feat_cnt;
     sifthip::DevBuf h_feat, h_hist;
 
     sifthip::Tuning tune;
@@ -211,6 +215,8 @@ void launch_warp_cylinder(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_sr
 int run_multiband_blend(sift_hip_ctx* ctx, uint8_t* d_l, int lw, int lh, uint8_t* d_r, int rw, int rh, int dx, int dy);
 void launch_compose_pair(sift_hip_ctx* ctx, hipStream_t st, const uint8_t* d_a, int ca, int ra, const uint8_t* d_b, int cb,
                          int rb, int top0, int left1, int top1, uint8_t* d_canvas, int cols, int rows);
+// descriptor bytes of n feature records, packed 128 per feature (match.hip)
+void launch_gather_descr(sift_hip_ctx* ctx, hipStream_t st, const sift_hip_feat* d_feat, int n, uint8_t* d_out);
 // n float samples to 8 bits the way ImgRaw's 8-bit copy does (Imgraw.hpp:59-82); d_dst 4-byte aligned
 void launch_float_to_u8(sift_hip_ctx* ctx, hipStream_t st, const float* d_src, size_t n, bool normalised, uint8_t* d_dst);
 // ransac.hip; features and best in device memory, outputs in host memory

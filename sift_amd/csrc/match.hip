@@ -422,4 +422,24 @@ int run_match_noalloc(sift_hip_ctx* ctx, const uint8_t* d_q, int nq, const uint8
     return SIFT_HIP_OK;
 }
 
+// ---- descriptors kept on the device (sift_hip_keep_descriptors) -------------------------------------
+// The 128 descriptor bytes of each record, packed: one 16-byte piece per thread.
+__global__ __launch_bounds__(256) void gather_descr_kernel(const sift_hip_feat* __restrict__ feat, int n,
+                                                           uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * 8) return;
+    const size_t f = i >> 3;
+    const int piece = (int)(i & 7);
+    const uint8_t* src = feat[f].descr + piece * 16;  // records are 4-byte aligned
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
+    uint4 v = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+    *reinterpret_cast<uint4*>(out + f * 128 + piece * 16) = v;
+}
+
+void launch_gather_descr(sift_hip_ctx* ctx, hipStream_t st, const sift_hip_feat* d_feat, int n, uint8_t* d_out) {
+    if (n <= 0) return;
+    const size_t threads = (size_t)n * 8;
+    gather_descr_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st>>>(d_feat, n, d_out);
+}
+
 }  // namespace sifthip

@@ -179,7 +179,13 @@ Sift::Sift(ImgRaw img, size_t intvls) : raw_img(std::move(img)), pyWidth(intvls 
     FeatEnd = FeatStart;
 }
 
-Sift::~Sift() { delete[] FeatStart; }
+Sift::~Sift() {
+    if (dev_descr) {
+        sift_amd::ContextUse use;
+        sift_hip_release_descriptors(use.ctx, (sift_hip_descr_set*)dev_descr);
+    }
+    delete[] FeatStart;
+}
 
 void Sift::pyramid() {
     if (raw_img.bitCount != 8 && raw_img.bitCount != 24) throw Size_error("Sift::pyramid: bitCount must be 8 or 24");
@@ -219,6 +225,22 @@ void Sift::pyramid() {
         check(ctx, rc, "sift_hip_extract");
         break;
     }
+    // the descriptor bytes stay on the device for Stitching::Match (the records are rewritten by the next extract)
+    if (dev_descr) {
+        sift_hip_release_descriptors(ctx, (sift_hip_descr_set*)dev_descr);
+        dev_descr = nullptr;
+        dev_descr_of = nullptr;
+        dev_descr_n = 0;
+    }
+    sift_hip_descr_set* kept = nullptr;
+    if (sift_amd::options().keep_descriptors && n > 0) {
+        int kn = 0;
+        check(ctx, sift_hip_keep_descriptors(ctx, &kept, &kn), "sift_hip_keep_descriptors");
+        if (kn != n) {  // cannot happen after a successful extract; never match stale data
+            sift_hip_release_descriptors(ctx, kept);
+            kept = nullptr;
+        }
+    }
     tm.step("sift_hip_extract");
     // refined positions (matrix.hpp:188-189); without refinement img_pt stays zero as in the reference
     std::vector<float> sub;
@@ -255,12 +277,18 @@ void Sift::pyramid() {
     FeatStart = arr;
     FeatEnd = arr + (n > 0 ? n - 1 : 0);
     feaNum = (size_t)n;
+    if (kept) {
+        dev_descr = kept;
+        dev_descr_of = arr;
+        dev_descr_n = (size_t)n;
+    }
     tm.step("Feature[] fill");
 }
 
 // ---- Stitching -------------------------------------------------------------------------
 Stitching::Stitching(const Sift& desc1, const Sift& desc2)
-    : feat1(desc1.FeatStart), feat2(desc2.FeatStart), feat1_Count(desc1.feaNum), feat2_Count(desc2.feaNum) {
+    : feat1(desc1.FeatStart), feat2(desc2.FeatStart), sift1(&desc1), sift2(&desc2), feat1_Count(desc1.feaNum),
+      feat2_Count(desc2.feaNum) {
     img1 = desc1.raw_img;
     img2 = desc2.raw_img;
     Width = img1.width + img2.width;
@@ -277,6 +305,21 @@ Stitching::Stitching(const Sift& desc1, const Sift& desc2)
 }
 
 size_t Stitching::Match(float matchTh) {
+    // Both feature arrays as pyramid() made them, their descriptor bytes still on the device: match those.
+    auto kept_of = [](const Sift* sf, const Feature* f, size_t n) -> sift_hip_descr_set* {
+        const bool ok = sift_amd::options().keep_descriptors && sf->dev_descr && sf->FeatStart == f && sf->feaNum == n &&
+                        sf->dev_descr_of == f && sf->dev_descr_n == n;
+        return ok ? (sift_hip_descr_set*)sf->dev_descr : nullptr;
+    };
+    sift_hip_descr_set* kq = kept_of(sift2, feat2, feat2_Count);
+    sift_hip_descr_set* kr = kept_of(sift1, feat1, feat1_Count);
+    if (kq && kr) {
+        std::vector<int32_t> best(feat2_Count);
+        sift_amd::ContextUse use;
+        check(use.ctx, sift_hip_match_kept(use.ctx, kq, kr, matchTh, sift_amd::options().ratio_form, best.data(), nullptr, nullptr),
+              "sift_hip_match_kept");
+        return link_matches(best);
+    }
     std::vector<uint8_t> q(feat2_Count * 128), r(feat1_Count * 128);
     auto pack = [](const Feature* f, size_t n, std::vector<uint8_t>& out) {
         uint8_t* dst = out.data();
@@ -295,6 +338,10 @@ size_t Stitching::Match(float matchTh) {
     sift_hip_ctx* ctx = use.ctx;
     check(ctx, sift_hip_match_u8(ctx, q.data(), (int)feat2_Count, r.data(), (int)feat1_Count, matchTh,
                                  sift_amd::options().ratio_form, best.data(), nullptr, nullptr), "sift_hip_match_u8");
+    return link_matches(best);
+}
+
+size_t Stitching::link_matches(const std::vector<int32_t>& best) {
     size_t accepted = 0;
     for (size_t i = 0; i < feat2_Count; i++) {
         if (best[i] >= 0) {

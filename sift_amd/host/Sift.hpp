@@ -54,6 +54,8 @@ struct Options {
     int textbook = 0;   // 1 = quality mode of sift_hip_params (not the reference's output)
     int ratio_form = 0; // 0 = d0 < d1*th (Sift.cpp:576), 1 = (d0/d1) < th (Sift.cpp:563)
     int ransac_on_gpu = 1; // Stitching::Check: 1 = sift_hip_ransac_homog, 0 = ransac_xform on the CPU (same result)
+    int keep_descriptors = 1; // Sift::pyramid keeps the descriptor bytes on the device and Stitching::Match matches those
+                              // (0 = descriptors packed from Feature[] and uploaded again; same result)
 };
 Options& options();
 // Wall time of the steps of a host call, printed to stderr when SIFT_HOST_TIMING=1.
@@ -97,6 +99,13 @@ public:
     Feature* FeatStart;  // contiguous Feature[feaNum] after pyramid(); owned
     Feature* FeatEnd;
     size_t feaNum = 0;
+    // The descriptor bytes of FeatStart[0..feaNum) as pyramid() left them in device memory (opaque handle of the
+    // C library, nullptr if none) and the array they describe.  Stitching::Match matches them directly while
+    // FeatStart / feaNum still are what pyramid() produced; a Feature[] the caller built or whose descriptors the
+    // caller edited must set dev_descr_of = nullptr (or options().keep_descriptors = 0) to be packed and uploaded.
+    void* dev_descr = nullptr;
+    const Feature* dev_descr_of = nullptr;
+    size_t dev_descr_n = 0;
 };
 
 class Stitching {
@@ -124,6 +133,8 @@ public:
 
 private:
     Feature *feat1, *feat2;
+    const Sift *sift1, *sift2;  // where the features came from (for the descriptors kept on the device)
+    size_t link_matches(const std::vector<int32_t>& best);  // best[i] -> feat2[i].fwd_match; returns the accepted count
     size_t Width, Height;
     ImgRaw stackImg;
     ImgRaw img1, img2;

@@ -128,6 +128,38 @@ int main(int argc, char** argv) {
             }
             fclose(wf);
         }
+        // Check() matched the descriptor bytes pyramid() kept on the device; packing Feature[] and uploading it
+        // again must link every feature to the same partner, and so must a second pyramid() of the same object
+        bool match_paths_equal = fea1.dev_descr && fea2.dev_descr;
+        {
+            std::vector<const Feature*> kept(fea2.feaNum);
+            for (size_t i = 0; i < fea2.feaNum; i++) kept[i] = fea2.FeatStart[i].fwd_match;
+            sift_amd::options().keep_descriptors = 0;
+            const size_t acc_packed = match.Match(th);
+            sift_amd::options().keep_descriptors = 1;
+            match_paths_equal = match_paths_equal && acc_packed == matched;
+            for (size_t i = 0; match_paths_equal && i < fea2.feaNum; i++) match_paths_equal = kept[i] == fea2.FeatStart[i].fwd_match;
+            // a Feature[] the caller edited: declared by clearing dev_descr_of, matched from the edited floats
+            if (fea2.feaNum > 0 && fea1.feaNum > 0) {
+                float saved[128];
+                std::memcpy(saved, fea2.FeatStart[0].descr, sizeof saved);
+                std::memcpy(fea2.FeatStart[0].descr, fea1.FeatStart[fea1.feaNum - 1].descr, sizeof saved);
+                const Feature* of = fea2.dev_descr_of;
+                fea2.dev_descr_of = nullptr;
+                match.Match(th);
+                std::vector<const Feature*> declared(fea2.feaNum);
+                for (size_t i = 0; i < fea2.feaNum; i++) declared[i] = fea2.FeatStart[i].fwd_match;
+                fea2.dev_descr_of = of;
+                sift_amd::options().keep_descriptors = 0;
+                match.Match(th);
+                sift_amd::options().keep_descriptors = 1;
+                for (size_t i = 0; match_paths_equal && i < fea2.feaNum; i++) match_paths_equal = declared[i] == fea2.FeatStart[i].fwd_match;
+                std::memcpy(fea2.FeatStart[0].descr, saved, sizeof saved);
+                fea2.dev_descr_of = of;
+                match.Match(th);
+                for (size_t i = 0; match_paths_equal && i < fea2.feaNum; i++) match_paths_equal = kept[i] == fea2.FeatStart[i].fwd_match;
+            }
+        }
         // the image-op mirrors: blur into the same vector must throw file_same
         bool threw = false;
         try { Gaus::GauBlur(img1.raw_img, img1.raw_img, w, h, 1.6f); } catch (const file_same&) { threw = true; }
@@ -170,9 +202,9 @@ int main(int argc, char** argv) {
                match.Panorama.width, match.Panorama.height,
                match.HomogMat.size() == 9 ? getFocal(match.HomogMat, img1.size(), img2.size()) : 0.f);
         printf("\"n1\": %zu, \"n2\": %zu, \"matched\": %zu, \"file_same\": %s, \"n_sub\": %zu, \"sub_sum_x\": %.6f, "
-               "\"sub_sum_y\": %.6f, \"ransac_equal\": %s, \"ransac_num\": %d, \"homog\": [",
+               "\"sub_sum_y\": %.6f, \"ransac_equal\": %s, \"match_paths_equal\": %s, \"ransac_num\": %d, \"homog\": [",
                fea1.feaNum, fea2.feaNum, matched, threw ? "true" : "false", fea3.feaNum, sx, sy, ransac_equal ? "true" : "false",
-               match.RANSAC_num);
+               match_paths_equal ? "true" : "false", match.RANSAC_num);
         for (size_t i = 0; i < match.HomogMat.size(); i++) printf("%s%.9g", i ? ", " : "", match.HomogMat[i]);
         printf("], \"ransac_feat\": [");
         for (int i = 0; i < match.RANSAC_num; i++) printf("%s%d", i ? ", " : "", (int)(match.RANSAC_feat[i] - fea2.FeatStart));

@@ -61,6 +61,8 @@ def test_cpp_classes_equal_c_abi_and_oracle(tmp_path, sift, oracle):
     mpts = np.stack([mp["x"] / mp["size"], mp["y"] / mp["size"]], axis=1).astype(np.float32)
     Ho, fin, in_min = ransac_oracle.ransac_xform(pts, mpts, 4, 0.005, 3.0, 1234)
     assert info["ransac_equal"] is True  # GPU (inside Check) == CPU ransac_xform
+    # matching the descriptors kept on the device == packing Feature[] and uploading it; an edited Feature[] is honoured
+    assert info["match_paths_equal"] is True
     assert Ho is not None and info["ransac_num"] == len(fin) >= in_min
     assert info["ransac_feat"] == [int(v) for v in sel[fin]]
     H = np.array(info["homog"])

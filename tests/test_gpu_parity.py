@@ -644,3 +644,34 @@ def test_page_locked_output_buffer(sift):
     assert sift.lib.sift_hip_host_alloc(sift.h, C.byref(p), 0) == sift_amd.capi.ERR_ARG
     assert sift.lib.sift_hip_host_alloc(sift.h, None, 16) == sift_amd.capi.ERR_ARG
     assert sift.lib.sift_hip_host_free(sift.h, None) == 0
+
+
+def test_descriptors_kept_on_the_device_match_like_uploaded_ones(sift):
+    """sift_hip_keep_descriptors / sift_hip_match_kept: the descriptor bytes of two extracts stay in device memory
+    and are matched there; indices and both distances must equal sift_hip_match_u8 on the descr bytes of the two
+    feature arrays that came back to the host, for both forms of the ratio test and for sets kept in either order;
+    a kept set survives later extracts on the same context; with nothing to keep the call is an argument error."""
+    fresh = sift_amd.SiftHip(0)
+    h = C.c_void_p()
+    assert fresh.lib.sift_hip_keep_descriptors(fresh.h, C.byref(h), None) == sift_amd.capi.ERR_ARG
+    del fresh
+    a = sift_amd.blob_image(640, 480, seed=5)
+    b = np.roll(a, (7, -11), axis=(0, 1)).copy()
+    prm = SiftParams(octaves=4)
+    fa, _ = sift.extract(a, prm)
+    ka, na = sift.keep_descriptors()
+    fb, _ = sift.extract(b, prm)
+    kb, nb = sift.keep_descriptors()
+    try:
+        assert na == len(fa) and nb == len(fb) and na > 100 and nb > 100
+        sift.extract(sift_amd.blob_image(320, 240, seed=9), prm)  # the records of both extracts are gone now
+        for form in (0, 1):
+            for (kq, fq, kr, fr) in ((kb, fb, ka, fa), (ka, fa, kb, fb)):
+                want = sift.match_u8(fq["descr"], fr["descr"], 0.5, form)
+                got = sift.match_kept(kq, kr, 0.5, form)
+                for w, g in zip(want, got):
+                    assert np.array_equal(w, g)
+                assert (got[0] >= 0).sum() > 50
+    finally:
+        sift.release_descriptors(ka)
+        sift.release_descriptors(kb)
