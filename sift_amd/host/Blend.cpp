@@ -124,9 +124,7 @@ void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::ve
     if (img1.bitCount != 24 || img2.bitCount != 24) throw std::runtime_error("blen2img: both images must be 24-bit RGB");
     if (!RANSAC_feat || RANSAC_num < 2) throw std::runtime_error("blen2img: needs at least two consensus matches");
     sift_amd::StepTimer tm("blen2img");
-    // The reference's 8-bit copies of both images (Blend.cpp:907-916) are made on the device from the float samples
-    // (sift_hip_panorama_pair_f32); focal length and alignment need the sizes only.
-    if (img1.nomal != img2.nomal) throw std::runtime_error("blen2img: both images must hold the same sample range");
+    // focal length and alignment need the sizes of the images only
     const Extent input[2] = {{(int)img1.width, (int)img1.height}, {(int)img2.width, (int)img2.height}};
     const float ft = getFocal(HomogMat, img1.size(), img2.size());
     int dx = 0, dy = 0;
@@ -147,16 +145,33 @@ void blen2img(const ImgRaw& img1, const ImgRaw& img2, ImgRaw& dst, const std::ve
     // warping (Blend.cpp:974), multiBandBlend (:994-996) and the canvas loops (:1010-1031; rows and
     // columns that leave the canvas are dropped, where the reference's buffer, tall enough for
     // images of up to 1500 rows only, has no guard) in one device call: two images up, the canvas down
-    std::vector<unsigned char> canvas;
-    sift_amd::reserve_large(canvas, (size_t)cols * rows2 * 3);
-    canvas.resize((size_t)cols * rows2 * 3);
+    // The 8-bit copies of both images (Blend.cpp:907-916, ImgRaw's conversion) are made by a few threads straight into
+    // a page-locked buffer kept beside the shared context, and the canvas comes back into the same buffer: both
+    // transfers are direct DMA (from the float vectors the upload alone would be four times the bytes through the
+    // runtime's staging copies).
+    const size_t n1 = (size_t)c0 * r0 * 3, n2 = (size_t)c1 * r1 * 3, nc = (size_t)cols * rows2 * 3;
+    const size_t off2 = (n1 + 255) / 256 * 256, offc = off2 + (n2 + 255) / 256 * 256;
+    static unsigned char* pin = nullptr;  // only touched while `use` holds the context lock
+    static size_t pin_cap = 0;
     {
         sift_amd::ContextUse use;
-        check(use.ctx, sift_hip_panorama_pair_f32(use.ctx, img1.raw_img.data(), c0, r0, img2.raw_img.data(), c1, r1, img1.nomal ? 1 : 0,
-                                                  ft, dx, blend_dy, top0, left1, top1, canvas.data(), cols, rows2),
-              "sift_hip_panorama_pair_f32");
+        if (offc + nc > pin_cap) {
+            sift_hip_host_free(use.ctx, pin);
+            pin = nullptr;
+            pin_cap = 0;
+            void* p = nullptr;
+            check(use.ctx, sift_hip_host_alloc(use.ctx, &p, offc + nc), "sift_hip_host_alloc");
+            pin = (unsigned char*)p;
+            pin_cap = offc + nc;
+        }
+        img1.to_bytes(pin);
+        img2.to_bytes(pin + off2);
+        tm.step("8-bit copies");
+        check(use.ctx, sift_hip_panorama_pair(use.ctx, pin, c0, r0, pin + off2, c1, r1, ft, dx, blend_dy, top0, left1, top1,
+                                              pin + offc, cols, rows2),
+              "sift_hip_panorama_pair");
+        tm.step("sift_hip_panorama_pair");
+        dst = ImgRaw(pin + offc, nc, (uint32_t)cols, (uint32_t)rows2, 24);
     }
-    tm.step("sift_hip_panorama_pair_f32");
-    dst = ImgRaw(canvas, (uint32_t)cols, (uint32_t)rows2, 24);
     tm.step("canvas to float");
 }

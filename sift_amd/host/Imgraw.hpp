@@ -85,15 +85,17 @@ public:
     ImgRaw(std::vector<types> img, uint32_t width, uint32_t height, uint16_t bits)
         : raw_img(std::move(img)), width(width), height(height), bitCount(bits) {}
     ImgRaw(const std::vector<unsigned char>& img, uint32_t width, uint32_t height, uint16_t bits)
+        : ImgRaw(img.data(), img.size(), width, height, bits) {}
+    // the same from n bytes anywhere (e.g. a page-locked transfer buffer)
+    ImgRaw(const unsigned char* src, size_t n, uint32_t width, uint32_t height, uint16_t bits)
         : width(width), height(height), bitCount(bits) {
-        sift_amd::reserve_large(raw_img, img.size());
-        raw_img.resize(img.size());
+        sift_amd::reserve_large(raw_img, n);
+        raw_img.resize(n);
         // (the 256 possible results of the reference's expression, Imgraw.hpp:30-41, tabulated)
         float lut[256];
         for (int v = 0; v < 256; ++v) lut[v] = nomal ? (float)(v / ImgRawPixMax) : (float)v;
-        const unsigned char* src = img.data();
         float* dst = raw_img.data();
-        sift_amd::parallel_for(img.size(), [=](size_t b, size_t e) {
+        sift_amd::parallel_for(n, [=](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) dst[i] = lut[src[i]];
         });
     }
@@ -107,8 +109,12 @@ public:
         std::vector<unsigned char> img;
         sift_amd::reserve_large(img, raw_img.size());
         img.resize(raw_img.size());
+        to_bytes(img.data());
+        return img;
+    }
+    // the same conversion into a buffer of size() bytes the caller provides
+    void to_bytes(unsigned char* dst) const {
         const float* src = raw_img.data();
-        unsigned char* dst = img.data();
         const bool scaled = nomal;
         sift_amd::parallel_for(raw_img.size(), [=](size_t b, size_t e) {
             if (scaled)
@@ -116,7 +122,6 @@ public:
             else
                 for (size_t i = b; i < e; ++i) dst[i] = (unsigned char)src[i];
         });
-        return img;
     }
     types& operator[](size_t idx) { return raw_img[idx]; }
     const types& operator[](size_t idx) const { return raw_img[idx]; }

@@ -55,9 +55,12 @@ int main(int argc, char** argv) {
     fclose(f);
     try {
         ImgRaw img1(a, w, h, (uint16_t)(8 * ch)), img2(b, w, h, (uint16_t)(8 * ch));
-        {   // warm-up (context creation, workspace growth), so that the times below are steady-state
-            Sift warm(img1);
-            warm.pyramid();
+        {   // warm-up (context creation, workspace and transfer-buffer growth), so that the times below are steady-state
+            Sift warm1(img1), warm2(img2);
+            warm1.pyramid();
+            warm2.pyramid();
+            Stitching warm(warm1, warm2);
+            warm.Check(th);
         }
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point t1) {
