@@ -1,38 +1,36 @@
 #!/usr/bin/env python3
-"""Median wall time of single 4K extracts on the blob frame and on the textured frame, with the serial per-class kernel
-times of the latter; run with SIFT_HIP_LIB=<variant build> to compare libraries:  python tools/frame_time.py [rounds]"""
+"""Wall time per frame of sift_hip_extract_dev (frame resident, page-locked feature array), for A/B runs of
+environment switches:  python tools/frame_time.py [--width W --height H --octaves N --blur-mode M --steps K]"""
+import argparse
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
 import sift_amd  # noqa: E402
 from sift_amd import SiftParams  # noqa: E402
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+ap = argparse.ArgumentParser()
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--octaves", type=int, default=4)
+ap.add_argument("--blur-mode", type=int, default=0)
+ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
 ctx = sift_amd.SiftHip(0)
-W, H = 3840, 2160
-frames = {"blob": torch.from_numpy(sift_amd.blob_image(W, H, seed=1)).cuda(),
-          "textured": torch.from_numpy(sift_amd.textured_image(W, H, seed=3)).cuda()}
+d = torch.from_numpy(sift_amd.blob_image(a.width, a.height, seed=1)).cuda()
 out = ctx.pinned_array(1 << 18, sift_amd.FEAT_DTYPE)
-prm = SiftParams(octaves=4)
-for r in range(rounds):
-    for name, d in frames.items():
-        for _ in range(10):
-            n = ctx.extract_dev(d, W, H, prm, out)
-        ts = []
-        for _ in range(60):
-            t0 = time.perf_counter()
-            ctx.extract_dev(d, W, H, prm, out)
-            ts.append((time.perf_counter() - t0) * 1e3)
-        print("%s round %d: median %.3f ms, features %s" % (name, r, float(np.median(ts)), n if isinstance(n, int) else len(n)), flush=True)
-ctx.profile(True)
-ctx.profile_read(reset=True)
-for _ in range(3):
-    ctx.extract_dev(frames["textured"], W, H, prm, out)
-pr = ctx.profile_read(reset=True)
-ctx.profile(False)
-print("textured, serial ms per class:", {k: round(v[0] / 3, 4) for k, v in pr.items() if v[1]})
+prm = SiftParams(octaves=a.octaves, blur_mode=a.blur_mode)
+for _ in range(25):
+    n = ctx.extract_dev(d, a.width, a.height, prm, out)
+res = []
+for _ in range(a.reps):
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        n = ctx.extract_dev(d, a.width, a.height, prm, out)
+    res.append((time.perf_counter() - t0) * 1e3 / a.steps)
+print("%dx%d octaves %d blur_mode %d: %d features, ms per frame %s" % (
+    a.width, a.height, a.octaves, a.blur_mode, n, " ".join("%.3f" % r for r in res)))
