@@ -672,6 +672,19 @@ def test_descriptors_kept_on_the_device_match_like_uploaded_ones(sift):
                 for w, g in zip(want, got):
                     assert np.array_equal(w, g)
                 assert (got[0] >= 0).sum() > 50
+        # after a batch call the kept set is the last frame's
+        frames = np.stack([a, b, np.roll(a, (3, 5), axis=(0, 1))])
+        outb, nbatch = sift.extract_batch(frames, prm)
+        kl, nl = sift.keep_descriptors()
+        try:
+            last = outb[2][: nbatch[2]]
+            assert nl == nbatch[2] > 100
+            want = sift.match_u8(last["descr"], fa["descr"], 0.5, 0)
+            got = sift.match_kept(kl, ka, 0.5, 0)
+            for w, g in zip(want, got):
+                assert np.array_equal(w, g)
+        finally:
+            sift.release_descriptors(kl)
     finally:
         sift.release_descriptors(ka)
         sift.release_descriptors(kb)
