@@ -262,7 +262,7 @@ static int octave_pyramid_step(sift_hip_ctx* ctx, OctWs& ws, hipStream_t st, con
         int rc;
         if ((rc = ensure(ctx, ws.base, PX * 4))) return rc;
         if ((rc = ensure(ctx, ws.tmp, PX * 4))) return rc;
-        if ((rc = ensure(ctx, ws.gau_all, PX * 4 * pyWidth))) return rc;
+        if ((rc = ensure(ctx, ws.gau_all, PX * 4 * pyWidth + 64))) return rc;  // (+64: the descriptor's 16-byte loads may run a few floats past the last row)
         launch_first(ctx, st, d_gray, pl.w, pl.h, oc.curr_size, (float*)ws.base.p, oc.W, oc.H);
         return SIFT_HIP_OK;
     }
@@ -322,7 +322,7 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
         const int nrows = prm.intvls * oc.H;
         if ((rc = ensure(ctx, ws->base, PX * 4))) return rc;
         if ((rc = ensure(ctx, ws->tmp, PX * 4))) return rc;
-        if ((rc = ensure(ctx, ws->gau_all, PX * 4 * (prm.intvls + 3)))) return rc;
+        if ((rc = ensure(ctx, ws->gau_all, PX * 4 * (prm.intvls + 3) + 64))) return rc;  // (+64: the descriptor's 16-byte loads may run a few floats past the last row)
         if ((rc = ensure(ctx, ws->masks, (size_t)nrows * WW * 8))) return rc;
         if ((rc = ensure(ctx, ws->row_cnt, (size_t)nrows * 4))) return rc;
         if ((rc = ensure(ctx, ws->row_off, (size_t)nrows * 4))) return rc;

@@ -28,7 +28,11 @@ constexpr int HSTRIDE = 129;
 constexpr float kFixScale = 1073741824.f;  // 2^30 units per 1.0; one addend is < 4
 constexpr int RCH = 512;                   // window rows handled per pass
 constexpr int NCHUNK = 2048;               // 64-sample chunks of a pass whose first row is tabulated
-constexpr int DU = 4;                      // samples in flight per thread
+constexpr int GU = 1;                      // groups of 4 consecutive samples in flight per thread (2 and 3 measured slower: registers)
+
+// four floats at any 4-byte aligned address (one 16-byte load: global memory takes unaligned accesses)
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
 // v is already scaled by kFixScale
 __device__ __forceinline__ unsigned long long to_fixed30(float v) { return (unsigned long long)(unsigned)v; }
@@ -128,7 +132,9 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
                             jlo = max(-radius, 1 - c);
                             clip_row(jlo, jhi, sin_t, (float)i * cos_t, L);
                             clip_row(jlo, jhi, cos_t, -(float)i * sin_t, L);
-                            len = max(0, jhi - jlo + 1);
+                            // (padded to whole groups of 4: a thread takes 4 consecutive samples of ONE row;
+                            // the samples past jhi fail the grid test below like any other sample outside it)
+                            len = (max(0, jhi - jlo + 1) + 3) & ~3;
                         }
                     }
                     int inc = len;
@@ -157,69 +163,91 @@ __global__ __launch_bounds__(1024) void descr_kernel(const float* __restrict__ g
             __syncthreads();
             const int total = s_off[nr];
             int row = 0;
-            // DU samples per thread and step: their 4*DU gradient loads are issued
-            // before any of them is consumed (the loop is otherwise bound by the
-            // latency of one gather per wave)
-            for (int idx0 = tid; idx0 < total; idx0 += DU * nthr) {
-                float px[DU][4], rb_[DU], cb_[DU], ww[DU];
-                bool ok[DU];
+            // A thread takes groups of 4 consecutive samples of one window row: one row search and one address per
+            // group, and the 14 pixels its 4 gradients need arrive in four loads (16 + 8 bytes of the row itself, 16 of
+            // the row above, 16 of the row below) that are contiguous across the lanes of a wave.  GU groups per
+            // thread and step are in flight before any is consumed.  Which thread adds a sample does not matter:
+            // the bins are integer sums.
+            const int ngroups = total >> 2;
+            for (int g0 = tid; g0 < ngroups; g0 += GU * nthr) {
+                float4u xa[GU], up[GU], dn[GU];
+                float2u xb[GU];
+                float rb_[GU][4], cb_[GU][4], ww[GU][4];
+                bool ok[GU][4], any[GU];
 #pragma unroll
-                for (int u = 0; u < DU; u++) {
-                    const int idx = idx0 + u * nthr;
-                    ok[u] = idx < total;
-                    if (ok[u]) {
+                for (int u = 0; u < GU; u++) {
+                    const int g = g0 + u * nthr;
+                    any[u] = false;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ok[u][e] = false;
+                    if (g < ngroups) {
+                        const int idx = g << 2;
                         if ((idx >> 6) < NCHUNK) row = s_chunk[idx >> 6];
                         while (idx >= s_off[row + 1]) row++;
                         const int i = row0 + row - radius;
-                        const int j = s_lo[row] + idx - s_off[row];
-                        const float fi_ = (float)i, fj = (float)j;
-                        const float c_rot = (fj * cos_t - fi_ * sin_t) * inv_hw;
-                        const float r_rot = (fj * sin_t + fi_ * cos_t) * inv_hw;
-                        rb_[u] = r_rot + 4 / 2.f - 0.5f;
-                        cb_[u] = c_rot + 4 / 2.f - 0.5f;
-                        ww[u] = c_rot * c_rot + r_rot * r_rot;
-                        ok[u] = rb_[u] > -1.f && rb_[u] < 4.f && cb_[u] > -1.f && cb_[u] < 4.f;
-                        if (ok[u]) {
-                            const unsigned p = (unsigned)((r + i) * W + (c + j));  // one level holds < 2^31 floats
-                            px[u][0] = img[p + 1u];
-                            px[u][1] = img[p - 1u];
-                            px[u][2] = img[p - (unsigned)W];
-                            px[u][3] = img[p + (unsigned)W];
+                        const int j0 = s_lo[row] + idx - s_off[row];
+                        const float fi_ = (float)i;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float fj = (float)(j0 + e);
+                            const float c_rot = (fj * cos_t - fi_ * sin_t) * inv_hw;
+                            const float r_rot = (fj * sin_t + fi_ * cos_t) * inv_hw;
+                            rb_[u][e] = r_rot + 4 / 2.f - 0.5f;
+                            cb_[u][e] = c_rot + 4 / 2.f - 0.5f;
+                            ww[u][e] = c_rot * c_rot + r_rot * r_rot;
+                            // (j0 + e <= jhi: the padding of a row lies outside the image interior at the right edge)
+                            ok[u][e] = rb_[u][e] > -1.f && rb_[u][e] < 4.f && cb_[u][e] > -1.f && cb_[u][e] < 4.f &&
+                                       c + j0 + e <= W - 2;
+                            any[u] = any[u] || ok[u][e];
+                        }
+                        if (any[u]) {
+                            const float* p = img + (unsigned)((r + i) * W + (c + j0));  // one level holds < 2^31 floats
+                            xa[u] = *reinterpret_cast<const float4u*>(p - 1);
+                            xb[u] = *reinterpret_cast<const float2u*>(p + 3);
+                            up[u] = *reinterpret_cast<const float4u*>(p - W);
+                            dn[u] = *reinterpret_cast<const float4u*>(p + W);
                         }
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < DU; u++) {
-                    if (!ok[u]) continue;
-                    const float rbin = rb_[u], cbin = cb_[u];
-                    const float dx = px[u][0] - px[u][1];
-                    const float dy = px[u][2] - px[u][3];
-                    const float mag = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
-                    float go = atan2_poly(dy, dx) - ori;
-                    go = (go + wrap_hi) + wrap_lo;
-                    if (go < 0.f) go += PI2;
-                    if (go >= PI2) go -= PI2;
-                    const float obin = go * bins_per_rad;
-                    const float w = __builtin_amdgcn_exp2f(ww[u] * exp_scale);
-                    const float m = mag * w * kFixScale;  // exact scaling by 2^30
-                    // interp_hist_entry (Sift.cpp:313-343)
-                    const float fr0 = floorf(rbin), fc0 = floorf(cbin), fo0 = floorf(obin);
-                    const int r0 = (int)fr0, c0 = (int)fc0, o0 = (int)fo0;
-                    const float d_r = rbin - fr0, d_c = cbin - fc0, d_o = obin - fo0;
-                    unsigned long long* hb = myhist + (r0 * 4 + c0) * 8;
-                    const int ob0 = o0 & 7, ob1 = (o0 + 1) & 7;
+                for (int u = 0; u < GU; u++) {
+                    if (!any[u]) continue;
+                    const float xs[6] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w, xb[u].x, xb[u].y};  // columns j0-1 .. j0+4
+                    const float us[4] = {up[u].x, up[u].y, up[u].z, up[u].w};
+                    const float ds[4] = {dn[u].x, dn[u].y, dn[u].z, dn[u].w};
 #pragma unroll
-                    for (int a = 0; a <= 1; a++) {
-                        const int rb = r0 + a;
-                        if (rb >= 0 && rb < 4) {
-                            const float v_r = m * ((a == 0) ? 1.f - d_r : d_r);
+                    for (int e = 0; e < 4; e++) {
+                        if (!ok[u][e]) continue;
+                        const float rbin = rb_[u][e], cbin = cb_[u][e];
+                        const float dx = xs[e + 2] - xs[e];
+                        const float dy = us[e] - ds[e];
+                        const float mag = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+                        float go = atan2_poly(dy, dx) - ori;
+                        go = (go + wrap_hi) + wrap_lo;
+                        if (go < 0.f) go += PI2;
+                        if (go >= PI2) go -= PI2;
+                        const float obin = go * bins_per_rad;
+                        const float w = __builtin_amdgcn_exp2f(ww[u][e] * exp_scale);
+                        const float m = mag * w * kFixScale;  // exact scaling by 2^30
+                        // interp_hist_entry (Sift.cpp:313-343)
+                        const float fr0 = floorf(rbin), fc0 = floorf(cbin), fo0 = floorf(obin);
+                        const int r0 = (int)fr0, c0 = (int)fc0, o0 = (int)fo0;
+                        const float d_r = rbin - fr0, d_c = cbin - fc0, d_o = obin - fo0;
+                        unsigned long long* hb = myhist + (r0 * 4 + c0) * 8;
+                        const int ob0 = o0 & 7, ob1 = (o0 + 1) & 7;
 #pragma unroll
-                            for (int b = 0; b <= 1; b++) {
-                                const int cb = c0 + b;
-                                if (cb >= 0 && cb < 4) {
-                                    const float v_c = v_r * ((b == 0) ? 1.f - d_c : d_c);
-                                    atomicAdd(&hb[(a * 4 + b) * 8 + ob0], to_fixed30(v_c * (1.f - d_o)));
-                                    atomicAdd(&hb[(a * 4 + b) * 8 + ob1], to_fixed30(v_c * d_o));
+                        for (int a = 0; a <= 1; a++) {
+                            const int rb = r0 + a;
+                            if (rb >= 0 && rb < 4) {
+                                const float v_r = m * ((a == 0) ? 1.f - d_r : d_r);
+#pragma unroll
+                                for (int b = 0; b <= 1; b++) {
+                                    const int cb = c0 + b;
+                                    if (cb >= 0 && cb < 4) {
+                                        const float v_c = v_r * ((b == 0) ? 1.f - d_c : d_c);
+                                        atomicAdd(&hb[(a * 4 + b) * 8 + ob0], to_fixed30(v_c * (1.f - d_o)));
+                                        atomicAdd(&hb[(a * 4 + b) * 8 + ob1], to_fixed30(v_c * d_o));
+                                    }
                                 }
                             }
                         }
