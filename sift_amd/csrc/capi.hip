@@ -212,6 +212,7 @@ static int build_plan(sift_hip_ctx* ctx, int w, int h, const sift_hip_params& pr
             oc.curr_sigma.push_back(cs);
             oc.wts_off.push_back((int)pl.table.size());
             pl.table.insert(pl.table.end(), g.begin(), g.end());
+            for (int z = 0; z < 4; z++) pl.table.push_back(0.f);  // the orientation kernel reads the weights four at a time
             while (pl.table.size() & 7) pl.table.push_back(0.f);
         }
         pl.oct.push_back(oc);

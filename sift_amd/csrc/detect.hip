@@ -627,21 +627,27 @@ __device__ __forceinline__ float fast_atan2f_deg(float dy, float dx) {
 // One wavefront per candidate.  The reference adds the weighted magnitudes into
 // the 36 bins one window pixel after another (row-major); float addition is not
 // associative and the ">= 0.8 * max" test decides how many features a keypoint
-// becomes, so the order of the additions is kept.  Per pass of ORI_CH window
-// pixels:
-//   A  all lanes evaluate magnitude and bin of their pixels (strided, coalesced)
-//   B  a stable counting sort by bin: lane l owns the ORI_RUN consecutive pixels
-//      RUN*l..RUN*l+RUN-1, counts them per bin with LDS atomics, lane b turns row b of
-//      the (bin x lane) count matrix into running offsets, and the pixels are
+// becomes, so the order of the additions is kept.  The window is numbered row by row with
+// its rows padded to a multiple of 4 slots (padding slots belong to no bin), and per pass of
+// ORI_CH slots:
+//   A  lane l evaluates magnitude and bin of the ORI_RUN consecutive slots RUN*l..RUN*l+RUN-1,
+//      two groups of 4 consecutive pixels of one window row: the 14 values of each of the two
+//      Gaussian levels that their 4 DoG gradients need arrive in four loads of 16 / 8 bytes
+//      instead of 8 scalar loads per pixel, and the results stay in the lane's registers
+//   B  a stable counting sort by bin: lane l counts its run per bin with LDS atomics, lane b
+//      turns row b of the (bin x lane) count matrix into running offsets, and the pixels are
 //      scattered to (bin, lane, rank) order -- window order within each bin
 //   C  lane b adds the values of bin b front to back.
 // Lane b touches only its own ~1/36 of the pixels instead of testing every pixel
 // against its bin number.
-constexpr int ORI_CH = 512;                 // pixels per pass (1024 and 2048 measured slower: fewer resident waves)
-constexpr int ORI_RUN = ORI_CH / 64;       // consecutive pixels a lane owns in the sort
-constexpr int ORI_BW = (ORI_RUN / 4) | 1;     // dwords per lane run of bin bytes (odd: conflict-free)
-constexpr int AU = 4;
+constexpr int ORI_CH = 512;                 // window slots per pass (1024 and 2048 measured slower: fewer resident waves)
+constexpr int ORI_RUN = ORI_CH / 64;       // consecutive slots a lane owns
 constexpr int ORI_ROW = 33;  // dwords per count-matrix row: 32 lane pairs (two u16 each) + 1 pad
+static_assert(ORI_RUN == 8, "a lane's run is two groups of 4 pixels");
+
+// four / two floats at any 4-byte aligned address (one load: global memory takes unaligned accesses)
+typedef float ori_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float ori_f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 // floor(th / 10) for th in [0, 360]: what (size_t)(sita / 10.0) yields in double
 // arithmetic (th / 10.0 is never within rounding distance of an integer unless th
@@ -659,12 +665,9 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
                                                     const float* __restrict__ table, const Cand* __restrict__ cand,
                                                     const int* __restrict__ counters,
                                                     unsigned long long* __restrict__ cmask, float* __restrict__ cmm) {
-    __shared__ float s_val[ORI_CH + ORI_CH / ORI_RUN];                      // pixel e at e + e/RUN
-    __shared__ unsigned s_binw[64 * ORI_BW];                                // bin of pixel e: byte (e/RUN)*4*BW + e%RUN
     __shared__ __attribute__((aligned(16))) unsigned s_cnt[37 * ORI_ROW + 59];  // 1280 dwords
     __shared__ float s_sorted[ORI_CH];
     __shared__ int s_base[36];
-    unsigned char* s_bin = reinterpret_cast<unsigned char*>(s_binw);
     const int lane = threadIdx.x;
     const int ncand = counters[CNT_NCAND];
     const unsigned half_shift = (lane & 1) * 16;
@@ -676,57 +679,85 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
         const LayerConsts L = lc[max(cd.layer, 1) - 1];
         const int r = L.radius;
         const int n = 2 * r + 1;
-        const int total = live ? n * n : 0;
+        const int n4 = (n + 3) & ~3;  // slots per window row
+        const int total = live ? n * n4 : 0;
         const float* g1 = gau + (size_t)cd.layer * PX;  // dog[layer] = gau[layer] - gau[layer+1]
         const float* g2 = g1 + PX;
         const float* g = table + L.wts_off;
-        // window position of this lane's element, advanced by 64 elements per step
-        const int di = 64 / n, dj = 64 - di * n;
-        int jj = lane / n;
-        int ii = lane - jj * n;
+        // window position (row jj, slot ii) of this lane's first slot, advanced by ORI_CH slots per pass
+        const int dj = ORI_CH / n4, di = ORI_CH - dj * n4;
+        int jj = (ORI_RUN * lane) / n4;
+        int ii = ORI_RUN * lane - jj * n4;
         float sum = 0.f;
         for (int e0 = 0; e0 < total; e0 += ORI_CH) {
-            const int cnt = min(ORI_CH, total - e0);
-            // ---- A: magnitude and bin of every pixel of the pass
-            // (AU pixels per lane and step: their 8*AU loads are issued before any is used)
-            for (int eb = lane; eb < cnt; eb += 64 * AU) {
-                float q[AU][8], wgt_i[AU], wgt_j[AU];
+            const int cnt = min(ORI_CH, total - e0);  // a multiple of 4
+            const int run0 = lane * ORI_RUN;
+            // ---- A: magnitude and bin of this lane's run (all 16 loads are issued before any is used)
+            ori_f4u xa[2][2], up[2][2], dn[2][2], wi[2];
+            ori_f2u xb[2][2];
+            float wj[2];
+            int gi[2];
+            bool in[2];
 #pragma unroll
-                for (int u = 0; u < AU; u++) {
-                    if (eb + 64 * u < cnt) {
-                        const unsigned p = (unsigned)((cd.y - r + jj) * W + (cd.x - r + ii));
-                        q[u][0] = g1[p + 1u];
-                        q[u][1] = g2[p + 1u];
-                        q[u][2] = g1[p - 1u];
-                        q[u][3] = g2[p - 1u];
-                        q[u][4] = g1[p + (unsigned)W];
-                        q[u][5] = g2[p + (unsigned)W];
-                        q[u][6] = g1[p - (unsigned)W];
-                        q[u][7] = g2[p - (unsigned)W];
-                        wgt_i[u] = g[ii];
-                        wgt_j[u] = g[jj];
-                        ii += dj;
-                        jj += di;
-                        if (ii >= n) {
-                            ii -= n;
-                            jj++;
-                        }
-                    }
+            for (int q = 0; q < 2; q++) {
+                int gj = jj;
+                gi[q] = ii + 4 * q;
+                if (gi[q] >= n4) {
+                    gi[q] -= n4;
+                    gj++;
                 }
+                in[q] = run0 + 4 * q < cnt;
+                if (in[q]) {
+                    const unsigned p = (unsigned)((cd.y - r + gj) * W + (cd.x - r + gi[q]));
 #pragma unroll
-                for (int u = 0; u < AU; u++) {
-                    const int e = eb + 64 * u;
-                    if (e < cnt) {
-                        const float dx = (q[u][0] - q[u][1]) - (q[u][2] - q[u][3]);
-                        const float dy = (q[u][4] - q[u][5]) - (q[u][6] - q[u][7]);
+                    for (int k = 0; k < 2; k++) {
+                        const float* lv = k ? g2 : g1;
+                        xa[q][k] = *reinterpret_cast<const ori_f4u*>(lv + p - 1u);
+                        xb[q][k] = *reinterpret_cast<const ori_f2u*>(lv + p + 3u);
+                        up[q][k] = *reinterpret_cast<const ori_f4u*>(lv + p - (unsigned)W);
+                        dn[q][k] = *reinterpret_cast<const ori_f4u*>(lv + p + (unsigned)W);
+                    }
+                    wi[q] = *reinterpret_cast<const ori_f4u*>(g + gi[q]);
+                    wj[q] = g[gj];
+                }
+            }
+            float val[ORI_RUN];
+            unsigned bin[ORI_RUN];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                // DoG values of the row: columns gi-1 .. gi+4
+                const float x1[6] = {xa[q][0].x, xa[q][0].y, xa[q][0].z, xa[q][0].w, xb[q][0].x, xb[q][0].y};
+                const float x2[6] = {xa[q][1].x, xa[q][1].y, xa[q][1].z, xa[q][1].w, xb[q][1].x, xb[q][1].y};
+                const float u1[4] = {up[q][0].x, up[q][0].y, up[q][0].z, up[q][0].w};
+                const float u2[4] = {up[q][1].x, up[q][1].y, up[q][1].z, up[q][1].w};
+                const float d1[4] = {dn[q][0].x, dn[q][0].y, dn[q][0].z, dn[q][0].w};
+                const float d2[4] = {dn[q][1].x, dn[q][1].y, dn[q][1].z, dn[q][1].w};
+                const float wv[4] = {wi[q].x, wi[q].y, wi[q].z, wi[q].w};
+                float dogx[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) dogx[k] = x1[k] - x2[k];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int t = 4 * q + e;
+                    val[t] = 0.f;
+                    bin[t] = 36u;  // padding slots and slots past the window: no bin
+                    if (in[q] && gi[q] + e < n) {
+                        const float dx = dogx[e + 2] - dogx[e];
+                        const float dy = (d1[e] - d2[e]) - (u1[e] - u2[e]);
                         float mag = sqrtf(dx * dx + dy * dy);
                         const float th = fast_atan2f_deg(dy, dx);
-                        mag = mag * wgt_i[u];
-                        mag = mag * wgt_j[u];
-                        s_val[e + e / ORI_RUN] = mag;
-                        s_bin[(e / ORI_RUN) * (4 * ORI_BW) + (e % ORI_RUN)] = (unsigned char)angle_bin(th);  // 36 == "one past the end": dropped
+                        mag = mag * wv[e];
+                        mag = mag * wj[q];
+                        val[t] = mag;
+                        bin[t] = (unsigned)angle_bin(th);  // 36 == "one past the end": dropped
                     }
                 }
+            }
+            ii += di;
+            jj += dj;
+            if (ii >= n4) {
+                ii -= n4;
+                jj++;
             }
             {
                 uint4* z = reinterpret_cast<uint4*>(s_cnt);
@@ -734,16 +765,10 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
                 for (int i = 0; i < 5; i++) z[i * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
             }
             __syncthreads();
-            // ---- B1: per-(bin, lane) counts of the lane's run of 16 pixels
-            unsigned bw[ORI_RUN / 4];
+            // ---- B1: per-(bin, lane) counts of the lane's run
 #pragma unroll
-            for (int i = 0; i < ORI_RUN / 4; i++) bw[i] = s_binw[lane * ORI_BW + i];
-            const int run0 = lane * ORI_RUN;
-#pragma unroll
-            for (int t = 0; t < ORI_RUN; t++) {
-                const unsigned b = (bw[t >> 2] >> ((t & 3) * 8)) & 0xffu;
-                if (run0 + t < cnt && b < 36u) atomicAdd(&s_cnt[b * ORI_ROW + (lane >> 1)], 1u << half_shift);
-            }
+            for (int t = 0; t < ORI_RUN; t++)
+                if (bin[t] < 36u) atomicAdd(&s_cnt[bin[t] * ORI_ROW + (lane >> 1)], 1u << half_shift);
             __syncthreads();
             // ---- B2: lane b turns row b into running offsets (lane order), then the
             // bins' totals into bin bases
@@ -772,11 +797,10 @@ __global__ __launch_bounds__(64) void orient_kernel(const float* __restrict__ ga
             // ---- B3: scatter to (bin, lane, rank) order
 #pragma unroll
             for (int t = 0; t < ORI_RUN; t++) {
-                const unsigned b = (bw[t >> 2] >> ((t & 3) * 8)) & 0xffu;
-                if (run0 + t < cnt && b < 36u) {
-                    const unsigned old = atomicAdd(&s_cnt[b * ORI_ROW + (lane >> 1)], 1u << half_shift);
-                    const int pos = s_base[b] + (int)((old >> half_shift) & 0xffffu);
-                    s_sorted[pos] = s_val[lane * (ORI_RUN + 1) + t];
+                if (bin[t] < 36u) {
+                    const unsigned old = atomicAdd(&s_cnt[bin[t] * ORI_ROW + (lane >> 1)], 1u << half_shift);
+                    const int pos = s_base[bin[t]] + (int)((old >> half_shift) & 0xffffu);
+                    s_sorted[pos] = val[t];
                 }
             }
             __syncthreads();
@@ -929,8 +953,9 @@ void launch_refine(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, int H, int in
 void launch_orient(sift_hip_ctx* ctx, OctWs& ws, size_t PX, int W, const LayerConsts* d_lc, const float* d_table) {
     ProfScope ps(ctx, SIFT_HIP_K_ORIENT, ws.stream);
     // persistent one-wave workgroups, as many as are resident at once (LDS-limited)
-    constexpr int lds_bytes = (ORI_CH + ORI_CH / ORI_RUN) * 4 + 64 * ORI_BW * 4 + (37 * ORI_ROW + 59) * 4 + ORI_CH * 4 + 36 * 4;
-    constexpr int per_cu = (160 * 1024 / lds_bytes) < 32 ? (160 * 1024 / lds_bytes) : 32;
+    constexpr int lds_bytes = (37 * ORI_ROW + 59) * 4 + ORI_CH * 4 + 36 * 4;
+    // (and register-limited: the kernel's 120-odd registers leave four waves per SIMD)
+    constexpr int per_cu = (160 * 1024 / lds_bytes) < 16 ? (160 * 1024 / lds_bytes) : 16;
     hipLaunchKernelGGL(orient_kernel, dim3(256 * per_cu), dim3(64), 0, ws.stream, (const float*)ws.gau_all.p, PX, W, d_lc,
                        d_table, (const Cand*)ws.cand.p, (const int*)ws.counters.p, (unsigned long long*)ws.cand_mask.p,
                        (float*)ws.cand_mm.p);
