@@ -447,7 +447,32 @@ __global__ __launch_bounds__(256) void top_check_kernel(const float* __restrict_
             const int row = min(max(y - 1 - r5 + t, 0), H - 1);
             const float* src = g_hi + (size_t)row * W;
             double a0 = 0, a1 = 0, a2 = 0;
-            if (inside) {
+            if (K <= 62 && c0 >= 0 && c0 + 64 <= W) {
+                // Short kernels (octave 0: 55 taps): the whole row of inputs in one burst of 16-byte loads
+                // before the first use -- the sweep then costs one trip to memory, where the loop below pays one
+                // per 16 taps and one per tap of its remainder (a candidate's time is nothing but such trips).
+                typedef float top_f4u __attribute__((ext_vector_type(4), aligned(4)));
+                const top_f4u* sp4 = reinterpret_cast<const top_f4u*>(src + c0);
+                float v[64];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const top_f4u q = sp4[j];
+                    v[4 * j] = q.x;
+                    v[4 * j + 1] = q.y;
+                    v[4 * j + 2] = q.z;
+                    v[4 * j + 3] = q.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 62; k++) {
+                    if (k < K) {  // uniform
+                        const float g = s_taps[k];
+                        const float p0 = v[k] * g, p1 = v[k + 1] * g, p2 = v[k + 2] * g;
+                        a0 += (double)p0;
+                        a1 += (double)p1;
+                        a2 += (double)p2;
+                    }
+                }
+            } else if (inside) {
                 const float* sp = src + c0;
                 float v0 = sp[0], v1 = sp[1];
 #pragma unroll 16
@@ -464,6 +489,7 @@ __global__ __launch_bounds__(256) void top_check_kernel(const float* __restrict_
             } else {
                 auto ld = [&](int j) { return src[min(max(c0 + j, 0), W - 1)]; };
                 float v0 = ld(0), v1 = ld(1);
+#pragma unroll 16
                 for (int k = 0; k < K; k++) {
                     const float v2 = ld(k + 2);
                     const float g = s_taps[k];
