@@ -222,20 +222,29 @@ def test_profile_counts_launches(sift):
 
 def test_lazy_top_level_equals_full_level(sift):
     """The last Gaussian level evaluated only at top-layer extrema must give the
-    features of the full-image evaluation (the library's A/B switch builds it)."""
+    features of the full-image evaluation (the library's A/B switch builds it).  The cases take the
+    check through each of its row sweeps: the burst of 16-byte loads (kernels of up to 62 taps on rows
+    with 64 pixels to read), the unrolled sweep (longer kernels: the deeper octaves, a larger sigma),
+    and the clamped sweep (octaves narrower than the kernel, where every window hangs over the border)."""
     import os
 
-    img = sift_amd.blob_image(640, 480, seed=3)
-    f, h = sift.extract(img, want_hist=True)
+    cases = [(sift_amd.blob_image(640, 480, seed=3), SiftParams()),
+             (sift_amd.blob_image(200, 150, seed=6), SiftParams()),
+             (sift_amd.textured_image(131, 97, seed=7), SiftParams()),
+             (sift_amd.blob_image(320, 240, seed=8), SiftParams(sigma0=2.0)),
+             (sift_amd.blob_image(320, 240, seed=9), SiftParams(sigma0=1.2, intvls=2))]
+    got = [sift.extract(img, prm, want_hist=True) for img, prm in cases]
     os.environ["SIFT_HIP_FULL_TOP"] = "1"
     try:
         other = sift_amd.SiftHip(0)
-        f2, h2 = other.extract(img, want_hist=True)
+        want = [other.extract(img, prm, want_hist=True) for img, prm in cases]
         other.close()
     finally:
         del os.environ["SIFT_HIP_FULL_TOP"]
-    assert (f["kai"] == 3).sum() > 20
-    assert f.tobytes() == f2.tobytes() and np.array_equal(h, h2)
+    assert (got[0][0]["kai"] == 3).sum() > 20
+    for (f, h), (f2, h2), (img, prm) in zip(got, want, cases):
+        assert (f["kai"] == prm.intvls).sum() > 0, img.shape  # the top layer has features at all
+        assert f.tobytes() == f2.tobytes() and np.array_equal(h, h2), img.shape
 
 
 def test_octave_placement_on_the_streams_changes_nothing(sift, oracle):
