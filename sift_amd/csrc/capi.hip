@@ -484,13 +484,15 @@ static int enqueue_extract(sift_hip_ctx* ctx, const float* d_gray, int w, int h,
 static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n, float* hist, int* cand_overflow,
                           hipStream_t st = nullptr, bool join_side = true) {
     if (!st) st = ctx->stream;
-    int early = 0;  // records of octave 0 whose copy is already under way
+    int early = 0;   // records of octave 0 whose copy is already under way
+    int early1 = 0;  // ... and of octave 1 (only if all of octave 0's are)
+    bool plain = false;
     if (join_side && ctx->side_busy) {
         // Octave 0 holds three quarters of the features and its stream is usually done while the
         // small octaves still drain: read its count and start its copy (on the copy stream) now.
         // (worth its extra counter read, about 10 us, only for frames with a long drain: 4 Mpixel and more)
-        const bool plain = !hist && ctx->plan.prm.subpixel == 0 && st == ctx->stream &&
-                           (size_t)ctx->plan.oct[0].W * ctx->plan.oct[0].H >= ((size_t)16 << 20);
+        plain = !hist && ctx->plan.prm.subpixel == 0 && st == ctx->stream &&
+                (size_t)ctx->plan.oct[0].W * ctx->plan.oct[0].H >= ((size_t)16 << 20);
         if (plain) {
             if (!hip_ok(ctx, hipStreamSynchronize(st), "extract (octave 0)")) return SIFT_HIP_ERR_HIP;
             std::memcpy(ctx->h_counters, ctx->gcounters.p, G_SLOTS * sizeof(int));
@@ -503,8 +505,22 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
                     return SIFT_HIP_ERR_HIP;
             }
         }
-        if (!hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)") ||
-            !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream2), "extract (second side stream)") ||
+        if (!hip_ok(ctx, hipStreamSynchronize(ctx->side_stream), "extract (side stream)")) return SIFT_HIP_ERR_HIP;
+        // Octave 1 likewise (its stream is joined now, the deeper octaves' stream usually not yet): its records go
+        // behind octave 0's, whose count is final.
+        if (plain && early > 0 && early == ctx->h_counters[G_OCT_FEATS] && ctx->plan.oct.size() > 2) {
+            const volatile int* gc = (const volatile int*)ctx->gcounters.p;
+            int found1 = gc[G_OCT_CAND + 1];
+            if (ctx->lanes[1].lazy_top) found1 = std::max(found1, (int)gc[G_OCT_CAND_TOP + 1]);
+            const int n1 = gc[G_OCT_FEATS + 1];
+            if (found1 <= ctx->cand_cap && n1 > 0 && n1 <= cap - early) {
+                if (!hip_ok(ctx, hipMemcpyAsync(out + early, ctx->lanes[1].feat.p, (size_t)n1 * sizeof(sift_hip_feat),
+                                                hipMemcpyDeviceToHost, ctx->copy_stream), "read features"))
+                    return SIFT_HIP_ERR_HIP;
+                early1 = n1;
+            }
+        }
+        if (!hip_ok(ctx, hipStreamSynchronize(ctx->side_stream2), "extract (second side stream)") ||
             !hip_ok(ctx, hipStreamSynchronize(ctx->side_stream3), "extract (third side stream)"))
             return SIFT_HIP_ERR_HIP;
     }
@@ -517,7 +533,7 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
         if (found > ctx->cand_cap) *cand_overflow = std::max(*cand_overflow, found);
     }
     if (*cand_overflow) {
-        if (early > 0) hipStreamSynchronize(ctx->copy_stream);  // the caller's array is rewritten by the next attempt
+        if (early > 0 || early1 > 0) hipStreamSynchronize(ctx->copy_stream);  // the caller's array is rewritten by the next attempt
         return SIFT_HIP_OK;
     }
     const int noct = (int)ctx->plan.oct.size();
@@ -538,7 +554,7 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
         ctx->last_feat_ptr[(size_t)oi] = (const sift_hip_feat*)ctx->lanes[oi].feat.p;
         ctx->last_feat_cnt[(size_t)oi] = m;
         if (m > 0) {
-            if (!(oi == 0 && early == m) &&
+            if (!(oi == 0 && early == m) && !(oi == 1 && early1 == m && early1 > 0) &&
                 !hip_ok(ctx, hipMemcpyAsync(out + copied, ctx->lanes[oi].feat.p, (size_t)m * sizeof(sift_hip_feat),
                                             hipMemcpyDeviceToHost, st), "read features"))
                 return SIFT_HIP_ERR_HIP;
@@ -556,7 +572,7 @@ static int fetch_features(sift_hip_ctx* ctx, sift_hip_feat* out, int cap, int* n
     }
     *n = (int)std::min<long long>(total, INT32_MAX);
     if (copied > 0 && !hip_ok(ctx, hipStreamSynchronize(st), "read features")) return SIFT_HIP_ERR_HIP;
-    if (early > 0 && !hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "read features (octave 0)")) return SIFT_HIP_ERR_HIP;
+    if ((early > 0 || early1 > 0) && !hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "read features (octaves 0, 1)")) return SIFT_HIP_ERR_HIP;
     return total > cap ? SIFT_HIP_ERR_NOSPC : SIFT_HIP_OK;
 }
 
